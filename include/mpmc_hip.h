@@ -1,0 +1,158 @@
+/*
+ * mpmc_hip.h -- C ABI of the MI355X (gfx950) per-step energy engine for MPMC.
+ *
+ * This is the drop-in boundary for the reference's `double energy(system_t*)`
+ * hot path (reference src/energy/energy.c:67-226).  Plain C types only: the
+ * reference's C host code (src/energy/energy.c, where `#ifdef CUDA` spawns
+ * `polar_cuda()` today, energy.c:108-129 and :181-186) binds these entry points
+ * directly; INTEGRATION.md shows the patch.  The same library is what the
+ * repo's own host layer (host/*.c, mirroring system_t/energy()) and the Python
+ * tests (ctypes) call.
+ *
+ * Conventions
+ *   - every call returns 0 on success, <0 on error (message: mpmc_hip_last_error());
+ *     mirrors the reference plugin's "print and carry on" only in that nothing aborts
+ *     (reference src/polarization_gpu/polar_cuda_pcg.cu:205-219).
+ *   - SCF non-convergence is NOT an error: result.iter_success = 1, the reference's
+ *     (misnamed) failure flag (reference src/polarization/thole_iterative.c:199-210),
+ *     which the caller copies to system->iter_success so mc.c:322 rejects the move.
+ *   - all arithmetic fp64; units as in the reference: K, Angstrom, charges in
+ *     sqrt(K*A) (e * 408.7816, reference src/io/read_pqr.c:249), alpha in A^3.
+ *   - host buffers are caller-owned; the context keeps device-resident SoA copies.
+ *   - one context per device and per MC walker; a context is not thread-safe.
+ *   - there is NO CPU fallback: every entry point fails if no gfx950 device is usable.
+ */
+#ifndef MPMC_HIP_H
+#define MPMC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPMC_HIP_ABI_VERSION 1
+
+typedef struct mpmc_hip_ctx mpmc_hip_ctx;
+typedef struct mpmc_hip_comm mpmc_hip_comm;
+
+/* Run-time switches.  Field names are the reference's config keywords
+ * (reference src/io/input.c:437-1255, defaults :1598-1667). */
+typedef struct mpmc_hip_params {
+    double temperature;        /* temperature (K); Feynman-Hibbs needs it                        */
+    int rd_only;               /* rd_only: skip electrostatics and polarization (energy.c:108,149) */
+    int rd_lrc;                /* rd_lrc (default 1): LJ long-range correction (lj.c:56-107)     */
+    int feynman_hibbs;         /* feynman_hibbs (lj.c:11-54, coulombic.c:115-146)                */
+    int feynman_hibbs_order;   /* feynman_hibbs_order: 2 or 4                                    */
+    int ewald_alpha_set;       /* ewald_alpha given explicitly (input.c:1093-1096)               */
+    double ewald_alpha;        /* else 3.5 / cutoff (pbc.c:73-74)                                */
+    int ewald_kmax;            /* ewald_kmax (default 7, defines.h:61)                           */
+    int polarization;          /* polarization on (Thole, iterative solver, exponential damping) */
+    double polar_damp;         /* polar_damp (lambda, e.g. 2.1304)                               */
+    int polar_max_iter;        /* polar_max_iter (default 10); must be 0 if polar_precision > 0  */
+    double polar_precision;    /* polar_precision in Debye (thole_iterative.c:104)               */
+    double polar_gamma;        /* polar_gamma (default 1): pre-conditioning / SOR / ESOR weight  */
+    int polar_gs;              /* polar_gs: Gauss-Seidel in atom order                           */
+    int polar_gs_ranked;       /* polar_gs_ranked: Gauss-Seidel in ranked order (pairs.c:337-360)*/
+    int polar_sor;             /* polar_sor                                                      */
+    int polar_esor;            /* polar_esor                                                     */
+    int polar_palmo;           /* polar_palmo: Palmo-Krimm extra contraction                     */
+    int polar_rrms;            /* polar_rrms: report dipole RRMS                                 */
+    int polar_zodid;           /* polar_zodid: dipoles = alpha*E, no iteration                   */
+    int polar_wolf;            /* polar_wolf: Wolf static field (thole_field.c:71-124)           */
+    double polar_wolf_alpha;   /* polar_wolf_alpha (a.k.a. polar_wolf_damp)                      */
+    int polar_ewald;           /* polar_ewald: Ewald static field (polar_ewald.c:38-174)         */
+    int polar_ewald_alpha_set; /* polar_ewald_alpha given explicitly                             */
+    double polar_ewald_alpha;  /* else 3.5 / cutoff (pbc.c:75-76)                                */
+} mpmc_hip_params;
+
+/* What energy() leaves in system->observables / nodestats (structs.h:152-162),
+ * plus the split of the Ewald sum and a status word. */
+typedef struct mpmc_hip_result {
+    double energy;              /* observables->energy              */
+    double rd_energy;           /* observables->rd_energy           */
+    double coulombic_energy;    /* observables->coulombic_energy    */
+    double polarization_energy; /* observables->polarization_energy */
+    double es_real, es_recip, es_self;
+    double dipole_rrms;         /* observables->dipole_rrms         */
+    double volume, cutoff, ewald_alpha, polar_ewald_alpha;
+    int polar_iterations;       /* nodestats->polarization_iterations */
+    int iter_success;           /* system->iter_success (1 = SCF FAILED to converge) */
+    int n_atoms;
+    int status;                 /* 0 ok; bit 0: non-finite energy */
+} mpmc_hip_result;
+
+/* Device time of the last mpmc_hip_energy() by kernel class, from HIP events
+ * recorded on the engine's own streams (milliseconds; count = launches). */
+typedef struct mpmc_hip_timings {
+    float pair_ms;        /* LJ + real-space Ewald pair kernel           */
+    float recip_ms;       /* reciprocal-space structure factors          */
+    float field_ms;       /* Thole static field                          */
+    float amatrix_ms;     /* A-matrix build (HBM-write bound)            */
+    float sweep_ms;       /* all dipole sweeps (HBM-read bound)          */
+    float palmo_ms;       /* Palmo-Krimm contraction                     */
+    float other_ms;       /* rank metric, reductions, finalisation       */
+    float total_ms;       /* first launch to last kernel end             */
+    int sweep_count;      /* number of sweep launches inside sweep_ms    */
+    int amatrix_count;
+} mpmc_hip_timings;
+
+const char *mpmc_hip_last_error(void);
+int mpmc_hip_abi_version(void);
+int mpmc_hip_device_count(void);
+
+/* Persistent context (replaces the per-call cudaMalloc/cublasCreate/free of the
+ * reference plugin, polar_cuda_pcg.cu:221-401).  max_atoms bounds every later upload. */
+int mpmc_hip_create(mpmc_hip_ctx **ctx, int device, int max_atoms);
+void mpmc_hip_destroy(mpmc_hip_ctx *ctx);
+
+void mpmc_hip_default_params(mpmc_hip_params *p);
+int mpmc_hip_set_params(mpmc_hip_ctx *ctx, const mpmc_hip_params *p);
+
+/* basis: rows = lattice vectors, row-major [3][3] (system->pbc->basis, input.c:1527-1561).
+ * pbc_cutoff = 0 => half the shortest lattice vector (pbc.c:13-34). */
+int mpmc_hip_set_box(mpmc_hip_ctx *ctx, const double basis[9], double pbc_cutoff);
+
+/* Full configuration, atoms in the reference's list order (molecule after molecule).
+ * molecule[i]: id of the molecule; a molecule is a contiguous run of equal ids.
+ * mass[i]: atomic mass (amu); molecular masses are summed here (pairs.c:364-385). */
+int mpmc_hip_upload(mpmc_hip_ctx *ctx, int n, const double *x, const double *y, const double *z,
+                    const double *charge, const double *polarizability, const double *epsilon,
+                    const double *sigma, const double *mass, const int *molecule, const uint8_t *frozen);
+
+/* New coordinates for atoms [first, first+count): the delta after one MC move
+ * (make_move perturbs one molecule, mc_moves.c:567). */
+int mpmc_hip_update_atoms(mpmc_hip_ctx *ctx, int first, int count, const double *x, const double *y,
+                          const double *z);
+
+/* One full energy() evaluation on the device. */
+int mpmc_hip_energy(mpmc_hip_ctx *ctx, mpmc_hip_result *out);
+
+/* Per-atom vectors of the last energy(): atom->mu, ef_static, ef_induced,
+ * ef_induced_change, each [n][3] (needed by write_dipole/write_field at corrtime,
+ * output.c:1029-1088).  Any pointer may be NULL. */
+int mpmc_hip_download_dipoles(mpmc_hip_ctx *ctx, double *mu, double *ef_static, double *ef_induced,
+                              double *ef_induced_change);
+
+/* system->A_matrix of the last energy(): [3n][3n] row-major (thole_matrix.c:38-146). */
+int mpmc_hip_download_amatrix(mpmc_hip_ctx *ctx, double *A);
+
+/* atom->rank_metric [n] and the final sweep order [n] (polar_gs_ranked). */
+int mpmc_hip_download_ranking(mpmc_hip_ctx *ctx, double *rank_metric, int *ranked_array);
+
+int mpmc_hip_get_timings(mpmc_hip_ctx *ctx, mpmc_hip_timings *t);
+
+/* Walker averaging over xGMI: replaces the MPI_Gather of observables every corrtime
+ * (mc.c:417-432).  id is a 128-byte RCCL unique id made on rank 0 and handed to the
+ * other ranks by the caller's own launcher (MPI, torchrun env, a file). */
+int mpmc_hip_comm_unique_id(unsigned char id[128]);
+int mpmc_hip_comm_create(mpmc_hip_comm **comm, mpmc_hip_ctx *ctx, int nranks, int rank,
+                         const unsigned char id[128]);
+int mpmc_hip_allreduce_observables(mpmc_hip_comm *comm, double *values, int count);
+void mpmc_hip_comm_destroy(mpmc_hip_comm *comm);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,114 @@
+// device_common.h -- shared device-side types and helpers (gfx950, wave64, fp64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mpmc {
+
+// reference src/include/defines.h:7-61
+constexpr double kHBAR2 = 1.11211999e-68;
+constexpr double kHBAR4 = 1.23681087e-136;
+constexpr double kKB = 1.3806503e-23;
+constexpr double kKB2 = 1.90619525e-46;
+constexpr double kM2A2 = 1.0e20;
+constexpr double kM2A4 = 1.0e40;
+constexpr double kAMU2KG = 1.66053873e-27;
+constexpr double kDEBYE2SKA = 85.10597636;
+constexpr double kMAXVALUE = 1.0e40;
+constexpr double kSMALL_dR = 1.0e-12;
+constexpr int kMAX_ITERATION_COUNT = 128;
+constexpr double kPI = 3.14159265358979323846;
+constexpr double kOneOverSqrtPi = 0.56418958354;  // reference src/polarization/thole_field.c:10
+
+constexpr int kWave = 64;
+
+enum AtomFlag : int { kFrozen = 1, kValid = 2 };
+
+// Periodic cell, passed by value (lands in SGPRs / kernarg).
+struct DevBox {
+    double b[3][3];   // basis, rows = lattice vectors
+    double rb[3][3];  // reciprocal_basis (matrix inverse), reference src/energy/pbc.c:47-63
+    double cutoff;
+    double volume;
+};
+
+// SoA view of the configuration resident in HBM.  All arrays have npad entries
+// (npad = n rounded up to 64); pad atoms carry flags = 0, q = alpha = eps = sig = 0.
+struct DevAtoms {
+    const double *x, *y, *z;
+    const double *q, *alpha, *eps, *sig, *molmass;
+    const int *mol;
+    const int *flags;
+    int n, npad;
+};
+
+// Minimum image exactly as the reference evaluates it (src/energy/pairs.c:230-290):
+// same operation order, no FMA contraction, so the lattice translation picked by
+// rint() -- and therefore r, rimg, dimg -- is bit-identical to the CPU path even for
+// pairs sitting exactly on a half-box tie (common for framework atoms on special positions).
+__device__ __forceinline__ void minimum_image(const DevBox &bx, double dx, double dy, double dz, double &r,
+                                              double &rimg, double &ox, double &oy, double &oz) {
+#pragma clang fp contract(off)
+    double i0 = bx.rb[0][0] * dx;
+    i0 = i0 + bx.rb[1][0] * dy;
+    i0 = i0 + bx.rb[2][0] * dz;
+    double i1 = bx.rb[0][1] * dx;
+    i1 = i1 + bx.rb[1][1] * dy;
+    i1 = i1 + bx.rb[2][1] * dz;
+    double i2 = bx.rb[0][2] * dx;
+    i2 = i2 + bx.rb[1][2] * dy;
+    i2 = i2 + bx.rb[2][2] * dz;
+    i0 = rint(i0);
+    i1 = rint(i1);
+    i2 = rint(i2);
+    double t0 = bx.b[0][0] * i0;
+    t0 = t0 + bx.b[1][0] * i1;
+    t0 = t0 + bx.b[2][0] * i2;
+    double t1 = bx.b[0][1] * i0;
+    t1 = t1 + bx.b[1][1] * i1;
+    t1 = t1 + bx.b[2][1] * i2;
+    double t2 = bx.b[0][2] * i0;
+    t2 = t2 + bx.b[1][2] * i1;
+    t2 = t2 + bx.b[2][2] * i2;
+    double ex = dx - t0, ey = dy - t1, ez = dz - t2;
+    double r2 = dx * dx;
+    r2 = r2 + dy * dy;
+    r2 = r2 + dz * dz;
+    double ri2 = ex * ex;
+    ri2 = ri2 + ey * ey;
+    ri2 = ri2 + ez * ez;
+    r = sqrt(r2);
+    double ri = sqrt(ri2);
+    if (ri != ri) {  // isnan(ri) fallback, pairs.c:279
+        rimg = r;
+        ox = dx;
+        oy = dy;
+        oz = dz;
+    } else {
+        rimg = ri;
+        ox = ex;
+        oy = ey;
+        oz = ez;
+    }
+}
+
+// 64-lane butterfly sum; every lane ends with the total (fixed order => deterministic).
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+}  // namespace mpmc

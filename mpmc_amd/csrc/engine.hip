@@ -1,0 +1,757 @@
+// engine.hip -- host side of the MI355X energy engine: persistent device context, kernel
+// orchestration for one energy() evaluation, and the extern "C" ABI of include/mpmc_hip.h.
+//
+// Control flow of mpmc_hip_energy() mirrors reference src/energy/energy.c:67-226:
+//   [polar]  rank metric -> A build -> static field -> SCF sweeps -> (Palmo) -> U_pol
+//   [lj]     fused pair kernel (LJ + FH) + cached long-range correction
+//   [es]     real-space part in the same pair kernel, reciprocal kernel, self term
+// All on one HIP stream per context; the only host<->device traffic per call is the moved
+// molecule's coordinates in and a 32-double result record out (the reference plugin re-allocated
+// and re-uploaded everything per call, polar_cuda_pcg.cu:221-401).
+#include "../../include/mpmc_hip.h"
+
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "device_common.h"
+#include "kernels_gs.h"
+#include "kernels_pair.h"
+#include "kernels_polar.h"
+
+using namespace mpmc;
+
+// ------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return -1;
+}
+
+#define HIPCHK(expr)                                                                           \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) return fail("MPMC_HIP: %s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                                          __FILE__, __LINE__);                                 \
+    } while (0)
+
+extern "C" const char *mpmc_hip_last_error(void) { return g_err.c_str(); }
+extern "C" int mpmc_hip_abi_version(void) { return MPMC_HIP_ABI_VERSION; }
+extern "C" int mpmc_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------
+enum TimeClass { T_PAIR = 0, T_RECIP, T_FIELD, T_AMAT, T_SWEEP, T_PALMO, T_OTHER, T_NCLASS };
+
+struct TimeRec {
+    int cls;
+    hipEvent_t a, b;
+};
+
+enum ResSlot {
+    R_RD_PAIR = 0,  // 4 pair channels: rd, es_real, es_intra, spare
+    R_ES_REAL = 1,
+    R_ES_INTRA = 2,
+    R_LRC = 4,
+    R_RECIP = 5,
+    R_SELF = 6,
+    R_UPOL = 7,
+    R_RRMS = 8,
+    R_RMIN = 9,
+    R_COUNT = 16
+};
+
+// scratch for the permuted (ranked) Gauss-Seidel problem
+struct PermScratch {
+    double *px = nullptr, *py = nullptr, *pz = nullptr, *palpha = nullptr;
+    int *pflags = nullptr;
+    double *es = nullptr, *mu_old = nullptr, *mu_new = nullptr, *y = nullptr;
+    int cap = 0;
+};
+
+struct mpmc_hip_ctx {
+    int device = 0;
+    int max_atoms = 0, max_npad = 0;
+    int n = 0, npad = 0;
+    hipStream_t stream = nullptr;
+    // SoA configuration (HBM)
+    double *d_x = nullptr, *d_y = nullptr, *d_z = nullptr, *d_q = nullptr, *d_alpha = nullptr, *d_eps = nullptr,
+           *d_sig = nullptr, *d_molmass = nullptr;
+    int *d_mol = nullptr, *d_flags = nullptr;
+    // polarization state
+    double *d_A = nullptr;
+    size_t A_capacity = 0;  // in doubles
+    double *d_Aperm = nullptr;
+    size_t Aperm_capacity = 0;
+    double *d_es = nullptr, *d_mu0 = nullptr, *d_mu1 = nullptr, *d_efind = nullptr, *d_efchg = nullptr,
+           *d_rrms = nullptr, *d_rank = nullptr, *d_gsy = nullptr, *d_munew = nullptr;
+    int *d_perm = nullptr;
+    unsigned long long *d_errmax = nullptr;
+    double *d_mu_final = nullptr;  // points at d_mu0 or d_mu1 after the last energy()
+    // scratch
+    double *d_pairpart = nullptr;   // [ntile*ntile][4]
+    double *d_fieldpart = nullptr;  // [nchunk][3][npad]
+    double *d_perk = nullptr;       // [nk]
+    KVec *d_kvec = nullptr;
+    int nk = 0;
+    double *d_res = nullptr;  // R_COUNT doubles
+    double *h_res = nullptr;  // pinned
+    unsigned long long *h_err = nullptr;  // pinned, 1 word
+    double *h_rank = nullptr;             // pinned, max_npad
+    int *h_perm = nullptr;                // pinned, max_npad
+    std::vector<int> perm;                // final sweep order (atoms)
+    PermScratch ps;
+    // host state
+    mpmc_hip_params par;
+    bool have_params = false, have_box = false, have_atoms = false;
+    double basis[3][3], recip[3][3];
+    double pbc_cutoff_in = 0.0, cutoff = 0.0, volume = 0.0, ewald_alpha = 0.0, polar_ewald_alpha = 0.0;
+    bool kvec_valid = false, lrc_valid = false;
+    double lrc_cached = 0.0;
+    int kvec_kmax = -1;
+    // timing
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_next = 0;
+    std::vector<TimeRec> recs;
+    hipEvent_t ev_first = nullptr, ev_last = nullptr;
+    bool timed = false;
+};
+
+static DevAtoms dev_atoms(const mpmc_hip_ctx *c) {
+    DevAtoms a;
+    a.x = c->d_x;
+    a.y = c->d_y;
+    a.z = c->d_z;
+    a.q = c->d_q;
+    a.alpha = c->d_alpha;
+    a.eps = c->d_eps;
+    a.sig = c->d_sig;
+    a.molmass = c->d_molmass;
+    a.mol = c->d_mol;
+    a.flags = c->d_flags;
+    a.n = c->n;
+    a.npad = c->npad;
+    return a;
+}
+
+static DevBox dev_box(const mpmc_hip_ctx *c) {
+    DevBox b;
+    for (int p = 0; p < 3; ++p)
+        for (int q = 0; q < 3; ++q) {
+            b.b[p][q] = c->basis[p][q];
+            b.rb[p][q] = c->recip[p][q];
+        }
+    b.cutoff = c->cutoff;
+    b.volume = c->volume;
+    return b;
+}
+
+static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+struct ScopedTimer {
+    mpmc_hip_ctx *c;
+    TimeRec r;
+    bool on;
+    ScopedTimer(mpmc_hip_ctx *ctx, int cls) : c(ctx), on(false) {
+        if (c->ev_next + 2 <= c->ev_pool.size()) {
+            r.cls = cls;
+            r.a = c->ev_pool[c->ev_next++];
+            r.b = c->ev_pool[c->ev_next++];
+            hipEventRecord(r.a, c->stream);
+            on = true;
+        }
+    }
+    ~ScopedTimer() {
+        if (on) {
+            hipEventRecord(r.b, c->stream);
+            c->recs.push_back(r);
+        }
+    }
+};
+
+extern "C" void mpmc_hip_default_params(mpmc_hip_params *p) {
+    memset(p, 0, sizeof(*p));
+    p->rd_lrc = 1;           // reference src/io/input.c:1630
+    p->ewald_kmax = 7;       // defines.h:61
+    p->polar_gamma = 1.0;    // input.c:1625
+    p->polar_max_iter = 10;  // input.c:1626
+    p->feynman_hibbs_order = 2;
+}
+
+extern "C" int mpmc_hip_create(mpmc_hip_ctx **out, int device, int max_atoms) {
+    if (!out || max_atoms <= 0) return fail("MPMC_HIP: create: bad arguments");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail("MPMC_HIP: no HIP device available (this engine has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail("MPMC_HIP: device %d out of range (%d present)", device, ndev);
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail("MPMC_HIP: device %d is %s; this engine is built for gfx950 (MI355X) only", device,
+                    prop.gcnArchName);
+    mpmc_hip_ctx *c = new mpmc_hip_ctx();
+    c->device = device;
+    c->max_atoms = max_atoms;
+    c->max_npad = round_up(max_atoms, 128);
+    mpmc_hip_default_params(&c->par);
+    const size_t np = (size_t)c->max_npad;
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+#define DALLOC(ptr, count, type) HIPCHK(hipMalloc((void **)&(ptr), (count) * sizeof(type)))
+    DALLOC(c->d_x, np, double);
+    DALLOC(c->d_y, np, double);
+    DALLOC(c->d_z, np, double);
+    DALLOC(c->d_q, np, double);
+    DALLOC(c->d_alpha, np, double);
+    DALLOC(c->d_eps, np, double);
+    DALLOC(c->d_sig, np, double);
+    DALLOC(c->d_molmass, np, double);
+    DALLOC(c->d_mol, np, int);
+    DALLOC(c->d_flags, np, int);
+    DALLOC(c->d_es, 3 * np, double);
+    DALLOC(c->d_mu0, 3 * np, double);
+    DALLOC(c->d_mu1, 3 * np, double);
+    DALLOC(c->d_efind, 3 * np, double);
+    DALLOC(c->d_efchg, 3 * np, double);
+    DALLOC(c->d_gsy, 3 * np, double);
+    DALLOC(c->d_munew, 3 * np, double);
+    DALLOC(c->d_rrms, np, double);
+    DALLOC(c->d_rank, np, double);
+    DALLOC(c->d_perm, np, int);
+    DALLOC(c->d_errmax, 256, unsigned long long);
+    const size_t ntile = np / 64;
+    DALLOC(c->d_pairpart, ntile * ntile * kPairChannels, double);
+    const size_t nchunk_max = std::max<size_t>(1, np / 64);
+    DALLOC(c->d_fieldpart, nchunk_max * 3 * np, double);
+    DALLOC(c->d_res, R_COUNT, double);
+#undef DALLOC
+    HIPCHK(hipHostMalloc((void **)&c->h_res, R_COUNT * sizeof(double), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&c->h_err, sizeof(unsigned long long), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&c->h_rank, np * sizeof(double), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&c->h_perm, np * sizeof(int), hipHostMallocDefault));
+    c->ev_pool.resize(2 * 512);
+    for (auto &e : c->ev_pool) HIPCHK(hipEventCreate(&e));
+    HIPCHK(hipEventCreate(&c->ev_first));
+    HIPCHK(hipEventCreate(&c->ev_last));
+    HIPCHK(hipMemsetAsync(c->d_res, 0, R_COUNT * sizeof(double), c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *out = c;
+    return 0;
+}
+
+extern "C" void mpmc_hip_destroy(mpmc_hip_ctx *c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    void *dptrs[] = {c->d_x,     c->d_y,     c->d_z,      c->d_q,         c->d_alpha,    c->d_eps,  c->d_sig,
+                     c->d_molmass, c->d_mol, c->d_flags,  c->d_A,         c->d_Aperm,    c->d_es,   c->d_mu0,
+                     c->d_mu1,   c->d_efind, c->d_efchg,  c->d_rrms,      c->d_rank,     c->d_gsy,  c->d_munew,
+                     c->d_perm,  c->d_errmax, c->d_pairpart, c->d_fieldpart, c->d_perk, c->d_kvec, c->d_res};
+    for (void *p : dptrs)
+        if (p) hipFree(p);
+    void *pptrs[] = {c->ps.px, c->ps.py, c->ps.pz, c->ps.palpha, c->ps.pflags, c->ps.es, c->ps.mu_old, c->ps.mu_new,
+                     c->ps.y};
+    for (void *p : pptrs)
+        if (p) hipFree(p);
+    if (c->h_res) hipHostFree(c->h_res);
+    if (c->h_err) hipHostFree(c->h_err);
+    if (c->h_rank) hipHostFree(c->h_rank);
+    if (c->h_perm) hipHostFree(c->h_perm);
+    for (auto &e : c->ev_pool) hipEventDestroy(e);
+    if (c->ev_first) hipEventDestroy(c->ev_first);
+    if (c->ev_last) hipEventDestroy(c->ev_last);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+// reference src/io/check_input.c:318-470 (the subset that concerns this path)
+extern "C" int mpmc_hip_set_params(mpmc_hip_ctx *c, const mpmc_hip_params *p) {
+    if (!c || !p) return fail("MPMC_HIP: set_params: null argument");
+    if (p->feynman_hibbs && p->feynman_hibbs_order != 2 && p->feynman_hibbs_order != 4)
+        return fail("MPMC_HIP: feynman_hibbs_order must be 2 or 4");
+    if (p->feynman_hibbs && !(p->temperature > 0.0)) return fail("MPMC_HIP: feynman_hibbs needs temperature > 0");
+    if (p->ewald_kmax < 0 || p->ewald_kmax > 32) return fail("MPMC_HIP: ewald_kmax out of range");
+    if (p->polarization) {
+        if (!(p->polar_damp > 0.0)) return fail("MPMC_HIP: damping factor must be specified (polar_damp > 0)");
+        if (p->polar_precision > 0.0 && p->polar_max_iter > 0)
+            return fail("MPMC_HIP: cannot specify both polar_precision and polar_max_iter, must pick one");
+        if (p->polar_precision < 0.0) return fail("MPMC_HIP: invalid polarization iterative precision specified");
+        if (p->polar_precision == 0.0 && p->polar_max_iter <= 0 && !p->polar_zodid)
+            return fail("MPMC_HIP: polar_max_iter must be > 0 when polar_precision is 0");
+        if (p->polar_sor && p->polar_esor) return fail("MPMC_HIP: cannot specify both SOR and ESOR SCF methods");
+        if (p->polar_gamma < 0.0) return fail("MPMC_HIP: invalid Pre-cond/SOR/ESOR gamma set");
+        if (p->polar_ewald) return fail("MPMC_HIP: polar_ewald static field is not implemented yet");
+    }
+    c->par = *p;
+    c->have_params = true;
+    c->kvec_valid = false;
+    return 0;
+}
+
+// reference src/energy/pbc.c:13-83
+extern "C" int mpmc_hip_set_box(mpmc_hip_ctx *c, const double basis[9], double pbc_cutoff) {
+    if (!c || !basis) return fail("MPMC_HIP: set_box: null argument");
+    double b[3][3];
+    for (int p = 0; p < 3; ++p)
+        for (int q = 0; q < 3; ++q) b[p][q] = basis[3 * p + q];
+    double vol = b[0][0] * (b[1][1] * b[2][2] - b[1][2] * b[2][1]);
+    vol += b[0][1] * (b[1][2] * b[2][0] - b[1][0] * b[2][2]);
+    vol += b[0][2] * (b[1][0] * b[2][1] - b[1][1] * b[2][0]);
+    if (!(vol > 0.0)) return fail("MPMC_HIP: invalid simulation box dimensions (volume %g)", vol);
+    double cutoff = pbc_cutoff;
+    if (cutoff == 0.0) {
+        double short_mag = kMAXVALUE;
+        for (int i = -5; i <= 5; i++)
+            for (int j = -5; j <= 5; j++)
+                for (int k = -5; k <= 5; k++) {
+                    if (i == 0 && j == 0 && k == 0) continue;
+                    double v[3];
+                    for (int q = 0; q < 3; q++) v[q] = i * b[0][q] + j * b[1][q] + k * b[2][q];
+                    const double mag = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+                    if (mag < short_mag) short_mag = mag;
+                }
+        cutoff = 0.5 * short_mag;
+    }
+    if (!(cutoff > 0.0)) return fail("MPMC_HIP: invalid cutoff");
+    const double iv = 1.0 / vol;
+    double rb[3][3];
+    rb[0][0] = iv * (b[1][1] * b[2][2] - b[1][2] * b[2][1]);
+    rb[0][1] = iv * (b[0][2] * b[2][1] - b[0][1] * b[2][2]);
+    rb[0][2] = iv * (b[0][1] * b[1][2] - b[0][2] * b[1][1]);
+    rb[1][0] = iv * (b[1][2] * b[2][0] - b[1][0] * b[2][2]);
+    rb[1][1] = iv * (b[0][0] * b[2][2] - b[0][2] * b[2][0]);
+    rb[1][2] = iv * (b[0][2] * b[1][0] - b[0][0] * b[1][2]);
+    rb[2][0] = iv * (b[1][0] * b[2][1] - b[1][1] * b[2][0]);
+    rb[2][1] = iv * (b[0][1] * b[2][0] - b[0][0] * b[2][1]);
+    rb[2][2] = iv * (b[0][0] * b[1][1] - b[0][1] * b[1][0]);
+    memcpy(c->basis, b, sizeof(b));
+    memcpy(c->recip, rb, sizeof(rb));
+    c->pbc_cutoff_in = pbc_cutoff;
+    c->cutoff = cutoff;
+    c->volume = vol;
+    c->have_box = true;
+    c->kvec_valid = false;
+    c->lrc_valid = false;
+    return 0;
+}
+
+extern "C" int mpmc_hip_upload(mpmc_hip_ctx *c, int n, const double *x, const double *y, const double *z,
+                               const double *charge, const double *polarizability, const double *epsilon,
+                               const double *sigma, const double *mass, const int *molecule,
+                               const uint8_t *frozen) {
+    if (!c) return fail("MPMC_HIP: upload: null context");
+    if (n <= 0 || n > c->max_atoms) return fail("MPMC_HIP: upload: n = %d outside (0, %d]", n, c->max_atoms);
+    if (!x || !y || !z || !charge || !polarizability || !epsilon || !sigma || !mass || !molecule || !frozen)
+        return fail("MPMC_HIP: upload: null array");
+    HIPCHK(hipSetDevice(c->device));
+    const int npad = round_up(n, 128);
+    std::vector<double> hx(npad, 0.0), hy(npad, 0.0), hz(npad, 0.0), hq(npad, 0.0), ha(npad, 0.0), he(npad, 0.0),
+        hs(npad, 0.0), hm(npad, 0.0);
+    std::vector<int> hmol(npad, -1), hfl(npad, 0);
+    int m = -1;
+    for (int i = 0; i < n; ++i) {
+        if (i == 0 || molecule[i] != molecule[i - 1]) ++m;  // contiguous runs, read_pqr.c:278-287
+        hmol[i] = m;
+        hx[i] = x[i];
+        hy[i] = y[i];
+        hz[i] = z[i];
+        hq[i] = charge[i];
+        ha[i] = polarizability[i];
+        he[i] = epsilon[i];
+        hs[i] = sigma[i];
+        hfl[i] = kValid | (frozen[i] ? kFrozen : 0);
+    }
+    for (int s = 0; s < n;) {  // molecule mass = sum of its atoms' masses (update_com, pairs.c:364-385)
+        int e = s;
+        double mm = 0.0;
+        while (e < n && hmol[e] == hmol[s]) mm += mass[e++];
+        for (int i = s; i < e; ++i) hm[i] = mm;
+        s = e;
+    }
+    // pad atoms: distinct molecule ids, far away; never valid
+    for (int i = n; i < npad; ++i) hmol[i] = -2 - i;
+    const size_t bd = npad * sizeof(double), bi = npad * sizeof(int);
+    HIPCHK(hipMemcpyAsync(c->d_x, hx.data(), bd, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_y, hy.data(), bd, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_z, hz.data(), bd, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_q, hq.data(), bd, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_alpha, ha.data(), bd, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_eps, he.data(), bd, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_sig, hs.data(), bd, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_molmass, hm.data(), bd, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_mol, hmol.data(), bi, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_flags, hfl.data(), bi, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->n = n;
+    c->npad = npad;
+    c->have_atoms = true;
+    c->lrc_valid = false;
+    c->perm.assign(n, 0);
+    std::iota(c->perm.begin(), c->perm.end(), 0);
+    return 0;
+}
+
+extern "C" int mpmc_hip_update_atoms(mpmc_hip_ctx *c, int first, int count, const double *x, const double *y,
+                                     const double *z) {
+    if (!c || !c->have_atoms) return fail("MPMC_HIP: update_atoms: no configuration uploaded");
+    if (first < 0 || count <= 0 || first + count > c->n)
+        return fail("MPMC_HIP: update_atoms: range [%d, %d) outside [0, %d)", first, first + count, c->n);
+    if (!x || !y || !z) return fail("MPMC_HIP: update_atoms: null array");
+    HIPCHK(hipSetDevice(c->device));
+    const size_t b = count * sizeof(double);
+    HIPCHK(hipMemcpyAsync(c->d_x + first, x, b, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_y + first, y, b, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_z + first, z, b, hipMemcpyHostToDevice, c->stream));
+    // pageable sources: make sure the copies are complete before the caller reuses its buffers
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// k-vector list in the reference's loop order (coulombic.c:56-70)
+static int build_kvectors(mpmc_hip_ctx *c) {
+    const int kmax = c->par.ewald_kmax;
+    std::vector<KVec> kv;
+    const double alpha = c->ewald_alpha;
+    for (int l0 = 0; l0 <= kmax; l0++)
+        for (int l1 = (!l0 ? 0 : -kmax); l1 <= kmax; l1++)
+            for (int l2 = ((!l0 && !l1) ? 1 : -kmax); l2 <= kmax; l2++) {
+                if (l0 * l0 + l1 * l1 + l2 * l2 > kmax * kmax) continue;
+                const int l[3] = {l0, l1, l2};
+                double k[3];
+                for (int p = 0; p < 3; p++) {
+                    k[p] = 0;
+                    for (int q = 0; q < 3; q++) k[p] += 2.0 * kPI * c->recip[p][q] * l[q];
+                }
+                const double k2 = k[0] * k[0] + k[1] * k[1] + k[2] * k[2];
+                KVec v;
+                v.kx = k[0];
+                v.ky = k[1];
+                v.kz = k[2];
+                v.w = std::exp(-k2 / (4.0 * alpha * alpha)) / k2;
+                kv.push_back(v);
+            }
+    if (c->d_kvec) {
+        hipFree(c->d_kvec);
+        c->d_kvec = nullptr;
+    }
+    if (c->d_perk) {
+        hipFree(c->d_perk);
+        c->d_perk = nullptr;
+    }
+    c->nk = (int)kv.size();
+    if (c->nk > 0) {
+        HIPCHK(hipMalloc((void **)&c->d_kvec, kv.size() * sizeof(KVec)));
+        HIPCHK(hipMalloc((void **)&c->d_perk, kv.size() * sizeof(double)));
+        HIPCHK(hipMemcpy(c->d_kvec, kv.data(), kv.size() * sizeof(KVec), hipMemcpyHostToDevice));
+    }
+    c->kvec_valid = true;
+    return 0;
+}
+
+static int ensure_amatrix(mpmc_hip_ctx *c, bool need_perm) {
+    const size_t need = (size_t)(3 * (size_t)c->npad) * (3 * (size_t)c->npad);
+    if (c->A_capacity < need) {
+        if (c->d_A) hipFree(c->d_A);
+        c->d_A = nullptr;
+        c->A_capacity = 0;
+        HIPCHK(hipMalloc((void **)&c->d_A, need * sizeof(double)));
+        c->A_capacity = need;
+    }
+    if (need_perm && c->Aperm_capacity < need) {
+        if (c->d_Aperm) hipFree(c->d_Aperm);
+        c->d_Aperm = nullptr;
+        c->Aperm_capacity = 0;
+        HIPCHK(hipMalloc((void **)&c->d_Aperm, need * sizeof(double)));
+        c->Aperm_capacity = need;
+    }
+    return 0;
+}
+
+#include "engine_polar.inc"
+
+extern "C" int mpmc_hip_energy(mpmc_hip_ctx *c, mpmc_hip_result *out) {
+    if (!c || !out) return fail("MPMC_HIP: energy: null argument");
+    if (!c->have_atoms) return fail("MPMC_HIP: energy: no configuration uploaded");
+    if (!c->have_box) return fail("MPMC_HIP: energy: no box set");
+    HIPCHK(hipSetDevice(c->device));
+    const mpmc_hip_params &P = c->par;
+    c->ewald_alpha = P.ewald_alpha_set ? P.ewald_alpha : 3.5 / c->cutoff;                    // pbc.c:73-74
+    c->polar_ewald_alpha = P.polar_ewald_alpha_set ? P.polar_ewald_alpha : 3.5 / c->cutoff;  // pbc.c:75-76
+    if (!P.rd_only && (!c->kvec_valid || c->kvec_kmax != P.ewald_kmax)) {
+        if (build_kvectors(c)) return -1;
+        c->kvec_kmax = P.ewald_kmax;
+    }
+    memset(out, 0, sizeof(*out));
+    c->ev_next = 0;
+    c->recs.clear();
+    hipEventRecord(c->ev_first, c->stream);
+
+    const DevAtoms a = dev_atoms(c);
+    const DevBox bx = dev_box(c);
+    const int ntile = c->npad / 64;
+    int polar_iterations = 0, iter_success = 0;
+
+    // ---- polarization first, as energy.c:108-129 does
+    const bool do_polar = !P.rd_only && P.polarization;
+    if (do_polar) {
+        if (run_polarization(c, a, bx, &polar_iterations, &iter_success)) return -1;
+    } else {
+        HIPCHK(hipMemsetAsync(c->d_res + R_UPOL, 0, 2 * sizeof(double), c->stream));
+    }
+
+    // ---- LJ long-range correction: parameters + volume only => cached (lj.c:56-107)
+    if (P.rd_lrc) {
+        if (!c->lrc_valid) {
+            ScopedTimer t(c, T_OTHER);
+            hipLaunchKernelGGL(lj_lrc_kernel, dim3(ntile, ntile), dim3(64), 0, c->stream, a, bx, c->d_pairpart);
+            hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, c->stream, c->d_pairpart, ntile * ntile, 1,
+                               c->d_res + R_LRC);
+            c->lrc_valid = true;
+        }
+    } else {
+        HIPCHK(hipMemsetAsync(c->d_res + R_LRC, 0, sizeof(double), c->stream));
+        c->lrc_valid = false;
+    }
+
+    // ---- fused pair kernel: LJ(+FH) and real-space Ewald(+FH, + intra-molecular screening)
+    {
+        ScopedTimer t(c, T_PAIR);
+        PairParams pp;
+        pp.ewald_alpha = c->ewald_alpha;
+        pp.temperature = P.temperature;
+        pp.rd_only = P.rd_only;
+        pp.fh_order = P.feynman_hibbs ? P.feynman_hibbs_order : 0;
+        const dim3 grid(ntile, ntile), block(64);
+        if (pp.fh_order == 0)
+            hipLaunchKernelGGL(pair_rd_es_kernel<0>, grid, block, 0, c->stream, a, bx, pp, c->d_pairpart);
+        else if (pp.fh_order == 2)
+            hipLaunchKernelGGL(pair_rd_es_kernel<2>, grid, block, 0, c->stream, a, bx, pp, c->d_pairpart);
+        else
+            hipLaunchKernelGGL(pair_rd_es_kernel<4>, grid, block, 0, c->stream, a, bx, pp, c->d_pairpart);
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, c->stream, c->d_pairpart, ntile * ntile,
+                           kPairChannels, c->d_res + R_RD_PAIR);
+    }
+
+    // ---- reciprocal + self
+    if (!P.rd_only) {
+        ScopedTimer t(c, T_RECIP);
+        if (c->nk > 0) {
+            hipLaunchKernelGGL(ewald_recip_kernel, dim3(c->nk), dim3(256), 0, c->stream, a, c->d_kvec, c->d_perk);
+            hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, c->stream, c->d_perk, c->nk, 1,
+                               c->d_res + R_RECIP);
+        } else {
+            HIPCHK(hipMemsetAsync(c->d_res + R_RECIP, 0, sizeof(double), c->stream));
+        }
+        hipLaunchKernelGGL(ewald_self_kernel, dim3(1), dim3(256), 0, c->stream, a, c->ewald_alpha,
+                           c->d_res + R_SELF);
+    } else {
+        HIPCHK(hipMemsetAsync(c->d_res + R_RECIP, 0, 2 * sizeof(double), c->stream));
+    }
+    hipEventRecord(c->ev_last, c->stream);
+    HIPCHK(hipMemcpyAsync(c->h_res, c->d_res, R_COUNT * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipGetLastError());
+    c->timed = true;
+
+    const double *r = c->h_res;
+    const double rd = r[R_RD_PAIR] + r[R_LRC];
+    const double real = r[R_ES_REAL] - r[R_ES_INTRA];
+    const double recip = P.rd_only ? 0.0 : r[R_RECIP] * (4.0 * kPI / c->volume);  // coulombic.c:92
+    const double self = P.rd_only ? 0.0 : r[R_SELF];
+    const double coul = P.rd_only ? 0.0 : real + recip + self;  // coulombic.c:36
+    const double upol = do_polar ? r[R_UPOL] : 0.0;
+    out->rd_energy = rd;
+    out->es_real = P.rd_only ? 0.0 : real;
+    out->es_recip = recip;
+    out->es_self = self;
+    out->coulombic_energy = coul;
+    out->polarization_energy = upol;
+    out->energy = rd + coul + upol;  // energy.c:196
+    out->dipole_rrms = do_polar ? r[R_RRMS] : 0.0;
+    out->volume = c->volume;
+    out->cutoff = c->cutoff;
+    out->ewald_alpha = c->ewald_alpha;
+    out->polar_ewald_alpha = c->polar_ewald_alpha;
+    out->polar_iterations = polar_iterations;
+    out->iter_success = iter_success;
+    out->n_atoms = c->n;
+    out->status = std::isfinite(out->energy) ? 0 : 1;
+    return 0;
+}
+
+extern "C" int mpmc_hip_download_dipoles(mpmc_hip_ctx *c, double *mu, double *ef_static, double *ef_induced,
+                                         double *ef_induced_change) {
+    if (!c || !c->have_atoms) return fail("MPMC_HIP: download_dipoles: no configuration");
+    HIPCHK(hipSetDevice(c->device));
+    const size_t b = 3 * (size_t)c->n * sizeof(double);
+    if (mu) {
+        if (!c->d_mu_final) return fail("MPMC_HIP: download_dipoles: no polarization energy evaluated yet");
+        HIPCHK(hipMemcpy(mu, c->d_mu_final, b, hipMemcpyDeviceToHost));
+    }
+    if (ef_static) HIPCHK(hipMemcpy(ef_static, c->d_es, b, hipMemcpyDeviceToHost));
+    if (ef_induced) HIPCHK(hipMemcpy(ef_induced, c->d_efind, b, hipMemcpyDeviceToHost));
+    if (ef_induced_change) HIPCHK(hipMemcpy(ef_induced_change, c->d_efchg, b, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int mpmc_hip_download_amatrix(mpmc_hip_ctx *c, double *A) {
+    if (!c || !c->d_A || !A) return fail("MPMC_HIP: download_amatrix: no A matrix built");
+    HIPCHK(hipSetDevice(c->device));
+    const size_t n3 = 3 * (size_t)c->n, lda = 3 * (size_t)c->npad;
+    HIPCHK(hipMemcpy2D(A, n3 * sizeof(double), c->d_A, lda * sizeof(double), n3 * sizeof(double), n3,
+                       hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int mpmc_hip_download_ranking(mpmc_hip_ctx *c, double *rank_metric, int *ranked_array) {
+    if (!c || !c->have_atoms) return fail("MPMC_HIP: download_ranking: no configuration");
+    HIPCHK(hipSetDevice(c->device));
+    if (rank_metric) HIPCHK(hipMemcpy(rank_metric, c->d_rank, c->n * sizeof(double), hipMemcpyDeviceToHost));
+    if (ranked_array) memcpy(ranked_array, c->perm.data(), c->n * sizeof(int));
+    return 0;
+}
+
+extern "C" int mpmc_hip_get_timings(mpmc_hip_ctx *c, mpmc_hip_timings *t) {
+    if (!c || !t) return fail("MPMC_HIP: get_timings: null argument");
+    memset(t, 0, sizeof(*t));
+    if (!c->timed) return 0;
+    HIPCHK(hipSetDevice(c->device));
+    float acc[T_NCLASS] = {0};
+    int cnt[T_NCLASS] = {0};
+    for (const TimeRec &r : c->recs) {
+        float ms = 0.f;
+        HIPCHK(hipEventSynchronize(r.b));
+        HIPCHK(hipEventElapsedTime(&ms, r.a, r.b));
+        acc[r.cls] += ms;
+        cnt[r.cls]++;
+    }
+    t->pair_ms = acc[T_PAIR];
+    t->recip_ms = acc[T_RECIP];
+    t->field_ms = acc[T_FIELD];
+    t->amatrix_ms = acc[T_AMAT];
+    t->sweep_ms = acc[T_SWEEP];
+    t->palmo_ms = acc[T_PALMO];
+    t->other_ms = acc[T_OTHER];
+    t->sweep_count = cnt[T_SWEEP];
+    t->amatrix_count = cnt[T_AMAT];
+    float tot = 0.f;
+    HIPCHK(hipEventElapsedTime(&tot, c->ev_first, c->ev_last));
+    t->total_ms = tot;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// RCCL (xGMI) averaging of walker observables.  librccl is bound lazily so that the energy
+// path has no hard dependency on it.
+// ------------------------------------------------------------------------------------------
+struct mpmc_hip_comm {
+    ncclComm_t nccl = nullptr;
+    mpmc_hip_ctx *ctx = nullptr;
+    double *d_buf = nullptr;
+    int cap = 0;
+};
+
+struct Rccl {
+    void *h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t,
+                              hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+static Rccl g_rccl;
+
+static int load_rccl() {
+    if (g_rccl.h) return 0;
+    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return fail("MPMC_HIP: cannot load librccl: %s", dlerror());
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(h, "ncclCommInitRank");
+    g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(h, "ncclAllReduce");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy)
+        return fail("MPMC_HIP: librccl lacks an expected symbol");
+    g_rccl.h = h;
+    return 0;
+}
+
+static int rccl_fail(const char *what, ncclResult_t rc) {
+    return fail("MPMC_HIP: %s failed: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
+}
+
+extern "C" int mpmc_hip_comm_unique_id(unsigned char id[128]) {
+    if (load_rccl()) return -1;
+    ncclUniqueId u;
+    static_assert(sizeof(ncclUniqueId) == 128, "RCCL unique id is 128 bytes");
+    const ncclResult_t rc = g_rccl.GetUniqueId(&u);
+    if (rc != ncclSuccess) return rccl_fail("ncclGetUniqueId", rc);
+    memcpy(id, u.internal, 128);
+    return 0;
+}
+
+extern "C" int mpmc_hip_comm_create(mpmc_hip_comm **out, mpmc_hip_ctx *ctx, int nranks, int rank,
+                                    const unsigned char id[128]) {
+    if (!out || !ctx || !id || nranks <= 0 || rank < 0 || rank >= nranks)
+        return fail("MPMC_HIP: comm_create: bad arguments");
+    if (load_rccl()) return -1;
+    HIPCHK(hipSetDevice(ctx->device));
+    mpmc_hip_comm *cm = new mpmc_hip_comm();
+    cm->ctx = ctx;
+    ncclUniqueId u;
+    memcpy(u.internal, id, 128);
+    const ncclResult_t rc = g_rccl.CommInitRank(&cm->nccl, nranks, u, rank);
+    if (rc != ncclSuccess) {
+        delete cm;
+        return rccl_fail("ncclCommInitRank", rc);
+    }
+    cm->cap = 64;
+    HIPCHK(hipMalloc((void **)&cm->d_buf, cm->cap * sizeof(double)));
+    *out = cm;
+    return 0;
+}
+
+// sum over walkers of a small observable vector (<= 64 doubles), in place
+extern "C" int mpmc_hip_allreduce_observables(mpmc_hip_comm *cm, double *values, int count) {
+    if (!cm || !values || count <= 0 || count > cm->cap) return fail("MPMC_HIP: allreduce: bad arguments");
+    mpmc_hip_ctx *c = cm->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(cm->d_buf, values, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    const ncclResult_t rc =
+        g_rccl.AllReduce(cm->d_buf, cm->d_buf, (size_t)count, ncclFloat64, ncclSum, cm->nccl, c->stream);
+    if (rc != ncclSuccess) return rccl_fail("ncclAllReduce", rc);
+    HIPCHK(hipMemcpyAsync(values, cm->d_buf, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" void mpmc_hip_comm_destroy(mpmc_hip_comm *cm) {
+    if (!cm) return;
+    if (cm->nccl && g_rccl.CommDestroy) g_rccl.CommDestroy(cm->nccl);
+    if (cm->d_buf) hipFree(cm->d_buf);
+    delete cm;
+}

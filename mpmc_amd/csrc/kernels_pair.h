@@ -1,0 +1,285 @@
+// kernels_pair.h -- O(N^2) pair-energy kernels: LJ (+Feynman-Hibbs), real-space Ewald
+// (+FH, + intra-molecular screening), LJ long-range correction, reciprocal-space Ewald.
+//
+// Replaces the linked pair-list walk of the reference (src/energy/pairs.c:293-361,
+// lj.c:165-276, coulombic.c:149-194): no pair list is stored; geometry is recomputed
+// on the fly from SoA coordinates.  One wave owns a 64-atom i-tile (lane = atom i), the
+// 64-atom j-tile is staged in LDS and broadcast to all lanes; energy partials are reduced
+// with 64-lane shuffles and summed in a fixed order by a finalisation kernel, so results
+// are bitwise reproducible run to run.
+#pragma once
+#include "device_common.h"
+
+namespace mpmc {
+
+struct PairParams {
+    double ewald_alpha;
+    double temperature;
+    int rd_only;
+    int fh_order;  // 0 = off, 2, 4
+};
+
+constexpr int kPairChannels = 4;  // rd, es_real, es_intra, (spare)
+
+struct JTile {
+    double x[kWave], y[kWave], z[kWave], q[kWave], eps[kWave], sig[kWave], mm[kWave];
+    int mol[kWave], flags[kWave];
+};
+
+__device__ __forceinline__ void load_jtile(JTile &t, const DevAtoms &a, int j0, int lane) {
+    int j = j0 + lane;  // j < npad always (grid covers npad/64 tiles)
+    t.x[lane] = a.x[j];
+    t.y[lane] = a.y[j];
+    t.z[lane] = a.z[j];
+    t.q[lane] = a.q[j];
+    t.eps[lane] = a.eps[j];
+    t.sig[lane] = a.sig[j];
+    t.mm[lane] = a.molmass[j];
+    t.mol[lane] = a.mol[j];
+    t.flags[lane] = a.flags[j];
+}
+
+// grid = (npad/64 [J], npad/64 [I]); block = 64 threads.  Tiles with J < I exit.
+template <int FH>
+__global__ __launch_bounds__(64) void pair_rd_es_kernel(DevAtoms a, DevBox bx, PairParams pp,
+                                                         double *__restrict__ partials) {
+    const int I = blockIdx.y, J = blockIdx.x;
+    const int lane = threadIdx.x;
+    double *out = partials + (size_t)(I * gridDim.x + J) * kPairChannels;
+    if (J < I) {
+        if (lane < kPairChannels) out[lane] = 0.0;
+        return;
+    }
+    __shared__ JTile t;
+    load_jtile(t, a, J * kWave, lane);
+    __syncthreads();
+
+    const int i = I * kWave + lane;
+    const double xi = a.x[i], yi = a.y[i], zi = a.z[i];
+    const double qi = a.q[i], epsi = a.eps[i], sigi = a.sig[i], mmi = a.molmass[i];
+    const int moli = a.mol[i], fli = a.flags[i];
+    const double rc = bx.cutoff;
+    const double alpha = pp.ewald_alpha;
+
+    double e_rd = 0.0, e_es = 0.0, e_intra = 0.0;
+
+    for (int jj = 0; jj < kWave; ++jj) {
+        const int j = J * kWave + jj;
+        const int flj = t.flags[jj];
+        // pair (i<j), both real atoms, not frozen-frozen (lj.c:193, coulombic.c:165)
+        bool act = (j > i) && (fli & kValid) && (flj & kValid) && !((fli & kFrozen) && (flj & kFrozen));
+        if (!act) continue;
+        double r, rimg, dx, dy, dz;
+        minimum_image(bx, xi - t.x[jj], yi - t.y[jj], zi - t.z[jj], r, rimg, dx, dy, dz);
+        const bool same = (moli == t.mol[jj]);
+        const double epsj = t.eps[jj], sigj = t.sig[jj], qj = t.q[jj];
+
+        // ---- repulsion/dispersion: lj.c:189-250, mixing pairs.c:200-211 (Lorentz-Berthelot)
+        const bool rd_excl = same || epsi == 0.0 || sigi == 0.0 || epsj == 0.0 || sigj == 0.0;
+        // sigma < 0 marks "attractive only" pairs, whose pair epsilon is never set in the
+        // reference (stays 0 from calloc): they contribute exactly 0.
+        if (!rd_excl && !(sigi < 0.0 || sigj < 0.0) && (rimg - kSMALL_dR < rc)) {
+            const double sig = 0.5 * (sigi + sigj);
+            const double eps = sqrt(epsi * epsj);
+            double sor = fabs(sig) / rimg;
+            double s6 = sor * sor * sor;
+            s6 *= s6;
+            const double s12 = s6 * s6;
+            double e = 4.0 * eps * (s12 - s6);
+            if (FH) {  // lj_fh_corr, lj.c:11-54
+                const double ir = 1.0 / rimg, ir2 = ir * ir, ir3 = ir2 * ir, ir4 = ir3 * ir;
+                const double mj = t.mm[jj];
+                const double rm = kAMU2KG * mmi * mj / (mmi + mj);
+                const double dE = -24.0 * eps * (2.0 * s12 - s6) * ir;
+                const double d2E = 24.0 * eps * (26.0 * s12 - 7.0 * s6) * ir2;
+                double corr = kM2A2 * (kHBAR2 / (24.0 * kKB * pp.temperature * rm)) * (d2E + 2.0 * dE / rimg);
+                if (FH >= 4) {
+                    const double d3E = -1344.0 * eps * (6.0 * s12 - s6) * ir3;
+                    const double d4E = 12096.0 * eps * (10.0 * s12 - s6) * ir4;
+                    corr += kM2A4 * (kHBAR4 / (1152.0 * kKB2 * pp.temperature * pp.temperature * rm * rm)) *
+                            (15.0 * dE * ir3 + 4.0 * d3E * ir + d4E);
+                }
+                e += corr;
+            }
+            e_rd += e;
+        }
+
+        // ---- real-space Ewald: coulombic.c:149-194
+        if (!pp.rd_only) {
+            const bool es_excl = same || qi == 0.0 || qj == 0.0;
+            if (!es_excl && !(rimg > rc)) {
+                const double erfc_term = erfc(alpha * rimg);
+                double e = qi * qj * erfc_term / rimg;
+                if (FH) {  // coulombic_real_FH, coulombic.c:115-146 (added WITHOUT q_i q_j, as the reference does)
+                    const double gaussian_term = exp(-alpha * alpha * rimg * rimg);
+                    const double rr = rimg * rimg;
+                    const double ir = 1.0 / rimg, ir2 = ir * ir, ir3 = ir * ir2, ir4 = ir2 * ir2;
+                    const double a2 = alpha * alpha, a3 = a2 * alpha, a4 = a3 * alpha;
+                    const double mj = t.mm[jj];
+                    const double rm = kAMU2KG * mmi * mj / (mmi + mj);
+                    const double sqrtpi = sqrt(kPI);
+                    const double du = -2.0 * alpha * gaussian_term / (rimg * sqrtpi) - erfc_term * ir2;
+                    const double d2u = (4.0 / sqrtpi) * gaussian_term * (a3 + 1.0 * ir2) + 2.0 * erfc_term * ir3;
+                    double fh = kM2A2 * (kHBAR2 / (24.0 * kKB * pp.temperature * rm)) * (d2u + 2.0 * du / rimg);
+                    if (FH >= 4) {
+                        const double d3u =
+                            (gaussian_term / sqrtpi) * (-8.0 * (a3 * a2) * rimg - 8.0 * a3 / rimg - 12.0 * alpha * ir3) -
+                            6.0 * erfc_term * ir4;
+                        const double d4u = (gaussian_term / sqrtpi) *
+                                               (8.0 * a3 * a2 + 16.0 * a3 * a4 * rr + 32.0 * a3 * ir2 + 48.0 * ir4) +
+                                           24.0 * erfc_term * (ir4 * ir);
+                        fh += kM2A4 *
+                              (kHBAR4 / (1152.0 * (kKB * kKB * pp.temperature * pp.temperature * rm * rm))) *
+                              (15.0 * du * ir3 + 4.0 * d3u / rimg + d4u);
+                    }
+                    e += fh;
+                }
+                e_es += e;
+            } else if (same && qi != 0.0 && qj != 0.0) {
+                // charge-to-screen term of excluded (same-molecule) pairs; uses the UN-imaged r
+                // (coulombic.c:181-182).  es-excluded pairs with a zero charge contribute exactly 0.
+                e_intra += qi * qj * erf(alpha * r) / r;
+            }
+        }
+    }
+
+    e_rd = wave_sum(e_rd);
+    e_es = wave_sum(e_es);
+    e_intra = wave_sum(e_intra);
+    if (lane == 0) {
+        out[0] = e_rd;
+        out[1] = e_es;
+        out[2] = e_intra;
+        out[3] = 0.0;
+    }
+}
+
+// LJ long-range correction: pair part over all non-frozen pairs with eps_ij*sig_ij != 0
+// (same-molecule pairs INCLUDED, lj.c:56-83) + per-atom self part (lj.c:85-107).  Depends only
+// on parameters and the volume, so it is evaluated at upload / box change, like the
+// reference's cached pair_ptr->lrc.
+__global__ __launch_bounds__(64) void lj_lrc_kernel(DevAtoms a, DevBox bx, double *__restrict__ partials) {
+    const int I = blockIdx.y, J = blockIdx.x;
+    const int lane = threadIdx.x;
+    double *out = partials + (size_t)(I * gridDim.x + J);
+    if (J < I) {
+        if (lane == 0) out[0] = 0.0;
+        return;
+    }
+    __shared__ double seps[kWave], ssig[kWave];
+    __shared__ int sfl[kWave];
+    seps[lane] = a.eps[J * kWave + lane];
+    ssig[lane] = a.sig[J * kWave + lane];
+    sfl[lane] = a.flags[J * kWave + lane];
+    __syncthreads();
+    const int i = I * kWave + lane;
+    const double epsi = a.eps[i], sigi = a.sig[i];
+    const int fli = a.flags[i];
+    const double rc = bx.cutoff;
+    double acc = 0.0;
+    for (int jj = 0; jj < kWave; ++jj) {
+        const int j = J * kWave + jj;
+        const int flj = sfl[jj];
+        if (!((j > i) && (fli & kValid) && (flj & kValid) && !((fli & kFrozen) && (flj & kFrozen)))) continue;
+        const double sigj = ssig[jj], epsj = seps[jj];
+        double sig, eps;
+        if (sigi < 0.0 || sigj < 0.0) {
+            sig = 0.5 * (fabs(sigi) + fabs(sigj));
+            eps = 0.0;  // never set for attractive-only pairs (pairs.c:201-203)
+        } else if (sigi == 0.0 || sigj == 0.0) {
+            sig = 0.0;
+            eps = sqrt(epsi * epsj);
+        } else {
+            sig = 0.5 * (sigi + sigj);
+            eps = sqrt(epsi * epsj);
+        }
+        if (eps != 0.0 && sig != 0.0) {
+            const double sc = fabs(sig) / rc;
+            double s3 = fabs(sig);
+            s3 *= s3 * s3;
+            const double sc3 = sc * sc * sc, sc9 = sc3 * sc3 * sc3;
+            acc += ((16.0 / 3.0) * kPI * eps * s3) * ((1.0 / 3.0) * sc9 - sc3) / bx.volume;
+        }
+    }
+    if (I == J) {  // self term once per atom, on the diagonal tile
+        if ((fli & kValid) && !(fli & kFrozen) && sigi != 0.0 && epsi != 0.0) {
+            const double sc = fabs(sigi) / rc;
+            double s3 = fabs(sigi);
+            s3 *= s3 * s3;
+            const double sc3 = sc * sc * sc, sc9 = sc3 * sc3 * sc3;
+            acc += ((16.0 / 3.0) * kPI * epsi * s3) * ((1.0 / 3.0) * sc9 - sc3) / bx.volume;
+        }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) out[0] = acc;
+}
+
+// Reciprocal-space Ewald (coulombic.c:42-95): one 256-thread block per k-vector computes the
+// structure factor over non-frozen charged atoms (un-wrapped coordinates) and stores
+// w_k |S(k)|^2; the k list (hemisphere, |l|^2 <= kmax^2) is built on the host in the
+// reference's loop order.
+struct KVec {
+    double kx, ky, kz, w;  // w = exp(-k^2/4a^2)/k^2
+};
+
+__global__ __launch_bounds__(256) void ewald_recip_kernel(DevAtoms a, const KVec *__restrict__ kv,
+                                                           double *__restrict__ per_k) {
+    const KVec k = kv[blockIdx.x];
+    double re = 0.0, im = 0.0;
+    for (int i = threadIdx.x; i < a.n; i += blockDim.x) {
+        const double q = a.q[i];
+        if ((a.flags[i] & kFrozen) || q == 0.0) continue;
+        const double ph = k.kx * a.x[i] + k.ky * a.y[i] + k.kz * a.z[i];
+        double s, c;
+        sincos(ph, &s, &c);
+        re += q * c;
+        im += q * s;
+    }
+    re = wave_sum(re);
+    im = wave_sum(im);
+    __shared__ double sre[4], sim[4];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+        sre[w] = re;
+        sim[w] = im;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double R = (sre[0] + sre[1]) + (sre[2] + sre[3]);
+        const double Im = (sim[0] + sim[1]) + (sim[2] + sim[3]);
+        per_k[blockIdx.x] = k.w * (R * R + Im * Im);
+    }
+}
+
+// Point self term (coulombic.c:97-112): -alpha/sqrt(pi) * sum q^2 over non-frozen atoms.
+// One block; fixed-order reduction.
+__global__ __launch_bounds__(256) void ewald_self_kernel(DevAtoms a, double ewald_alpha, double *__restrict__ out) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < a.n; i += blockDim.x) {
+        if (a.flags[i] & kFrozen) continue;
+        const double q = a.q[i];
+        acc -= ewald_alpha * q * q / sqrt(kPI);
+    }
+    acc = wave_sum(acc);
+    __shared__ double s[4];
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (s[0] + s[1]) + (s[2] + s[3]);
+}
+
+// Fixed-order sum of `count` rows of `channels` doubles each: out[c] = sum_r in[r][c].
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const double *__restrict__ in, int count, int channels,
+                                                           double *__restrict__ out) {
+    __shared__ double s[4];
+    for (int c = 0; c < channels; ++c) {
+        double acc = 0.0;
+        for (int r = threadIdx.x; r < count; r += blockDim.x) acc += in[(size_t)r * channels + c];
+        acc = wave_sum(acc);
+        if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) out[c] = (s[0] + s[1]) + (s[2] + s[3]);
+        __syncthreads();
+    }
+}
+
+}  // namespace mpmc

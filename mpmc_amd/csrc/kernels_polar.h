@@ -1,0 +1,382 @@
+// kernels_polar.h -- Thole polarization on gfx950: static field, A-matrix build,
+// dipole sweeps (Jacobi / SOR / ESOR; Gauss-Seidel lives in kernels_gs.h), Palmo-Krimm
+// contraction, polarization energy.
+//
+// Memory layout (HBM):
+//   A        : (3*npad) x (3*npad) fp64, row-major, ONE allocation (the reference keeps 3N
+//              separately malloc'd rows, thole_matrix.c:172-178).  Row 3i+p, column 3j+q holds
+//              T_ij[p][q]; diagonal blocks hold 1/alpha_i (1e40 for alpha = 0), as the reference.
+//   vectors  : mu, E_static, E_induced, ... interleaved as v[3i+p] so they line up with A's columns.
+// The sweep streams A exactly once (HBM-read bound: (3N)^2 * 8 bytes per sweep); the A build
+// streams it out once (HBM-write bound).
+#pragma once
+#include "device_common.h"
+
+namespace mpmc {
+
+// ---------------------------------------------------------------------------------------------
+// Static field (reference src/polarization/thole_field.c:39-124).  i-centric: lane = atom i,
+// loops over a chunk of j atoms staged through LDS; E_i = sum_j q_j * f(r) * dimg, which is what
+// the reference's pair loop accumulates into both partners (the displacement of the pair seen
+// from j is exactly -dimg).  Excludes frozen-frozen pairs, same-molecule pairs, r = 0 and
+// pairs beyond the cutoff (inclusive within 1e-12).
+// grid = (nchunk [x], npad/64 [y]); block = 64.  part layout [chunk][3][npad].
+// ---------------------------------------------------------------------------------------------
+enum FieldMode { kFieldBare = 0, kFieldWolf0 = 1, kFieldWolfA = 2 };
+
+struct FieldParams {
+    double wolf_alpha;
+    double cutoffterm;  // erfc(aR)/R^2 + 2a/sqrt(pi) exp(-a^2R^2)/R   (thole_field.c:82-83)
+    int chunk;          // j atoms per block (multiple of 64)
+};
+
+template <int MODE>
+__global__ __launch_bounds__(64) void static_field_kernel(DevAtoms a, DevBox bx, FieldParams fp,
+                                                           double *__restrict__ part) {
+    const int lane = threadIdx.x;
+    const int i = blockIdx.y * kWave + lane;
+    const int jbeg = blockIdx.x * fp.chunk;
+    __shared__ double sx[kWave], sy[kWave], sz[kWave], sq[kWave];
+    __shared__ int smol[kWave], sfl[kWave];
+
+    const double xi = a.x[i], yi = a.y[i], zi = a.z[i];
+    const int moli = a.mol[i], fli = a.flags[i];
+    const double rc = bx.cutoff;
+    const double rR = 1.0 / rc;
+    double ex = 0.0, ey = 0.0, ez = 0.0;
+
+    for (int j0 = jbeg; j0 < jbeg + fp.chunk && j0 < a.npad; j0 += kWave) {
+        __syncthreads();
+        sx[lane] = a.x[j0 + lane];
+        sy[lane] = a.y[j0 + lane];
+        sz[lane] = a.z[j0 + lane];
+        sq[lane] = a.q[j0 + lane];
+        smol[lane] = a.mol[j0 + lane];
+        sfl[lane] = a.flags[j0 + lane];
+        __syncthreads();
+        for (int jj = 0; jj < kWave; ++jj) {
+            const int j = j0 + jj;
+            const int flj = sfl[jj];
+            const double qj = sq[jj];
+            bool act = (j != i) && (fli & kValid) && (flj & kValid) && !((fli & kFrozen) && (flj & kFrozen)) &&
+                       (moli != smol[jj]) && (qj != 0.0);
+            if (!act) continue;
+            double r, rimg, dx, dy, dz;
+            minimum_image(bx, xi - sx[jj], yi - sy[jj], zi - sz[jj], r, rimg, dx, dy, dz);
+            if ((rimg - kSMALL_dR < rc) && (rimg != 0.0)) {
+                double f;
+                if (MODE == kFieldBare) {
+                    f = qj / (rimg * rimg * rimg);
+                } else if (MODE == kFieldWolf0) {
+                    const double rr = 1.0 / rimg;
+                    f = qj * (rr * rr - rR * rR) * rr;
+                } else {
+                    const double rr = 1.0 / rimg;
+                    const double al = fp.wolf_alpha;
+                    const double bigmess =
+                        erfc(al * rimg) * rr * rr + 2.0 * al * kOneOverSqrtPi * exp(-al * al * rimg * rimg) * rr;
+                    f = qj * (bigmess - fp.cutoffterm) * rr;
+                }
+                ex += f * dx;
+                ey += f * dy;
+                ez += f * dz;
+            }
+        }
+    }
+    const size_t base = (size_t)blockIdx.x * 3 * a.npad;
+    part[base + i] = ex;
+    part[base + a.npad + i] = ey;
+    part[base + 2 * (size_t)a.npad + i] = ez;
+}
+
+// es[3i+p] = sum over chunks (fixed order) [+ accumulate into existing when add != 0]
+__global__ __launch_bounds__(256) void field_reduce_kernel(const double *__restrict__ part, int nchunk, int npad,
+                                                            double *__restrict__ es, int add) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npad) return;
+    for (int p = 0; p < 3; ++p) {
+        double acc = add ? es[3 * i + p] : 0.0;
+        for (int c = 0; c < nchunk; ++c) acc += part[((size_t)c * 3 + p) * npad + i];
+        es[3 * i + p] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// A-matrix build (reference src/polarization/thole_matrix.c:38-146, exponential damping).
+// ALL pairs contribute (no cutoff, no exclusions, frozen-frozen included).  Lane = two adjacent
+// column atoms (j0, j0+1) so every row segment a wave writes is 64 x 48 B = 3 KiB contiguous,
+// stored as 16-byte vectors; the row atom i is wave-uniform (LDS broadcast).  Both (i,j) and
+// (j,i) blocks are computed independently -- T is even in the displacement, so they agree
+// bit-for-bit -- which keeps every store coalesced and needs no transposition pass.
+// grid = (npad/128 [column tiles], npad/kARows [row tiles]); block = 64.
+// ---------------------------------------------------------------------------------------------
+constexpr int kARows = 16;
+
+__device__ __forceinline__ void thole_tensor(const DevBox &bx, double damp, double dx0, double dy0, double dz0,
+                                             double &xx, double &xy, double &xz, double &yy, double &yz,
+                                             double &zz) {
+    double r, rimg, dx, dy, dz;
+    minimum_image(bx, dx0, dy0, dz0, r, rimg, dx, dy, dz);
+    double ir3, ir5;
+    if (rimg == 0.0) {
+        ir3 = ir5 = kMAXVALUE;  // thole_matrix.c:81-82
+    } else {
+        const double ir = 1.0 / rimg;
+        ir3 = ir * ir * ir;
+        ir5 = ir3 * ir * ir;
+    }
+    const double l = damp, l2 = l * l, l3 = l2 * l;
+    const double r2 = rimg * rimg;
+    const double explr = exp(-l * rimg);
+    const double damp1 = 1.0 - explr * (0.5 * l2 * r2 + l * rimg + 1.0);
+    const double damp2 = damp1 - explr * (l3 * r2 * rimg / 6.0);
+    const double c5 = damp2 * ir5, c3 = damp1 * ir3;
+    xx = -3.0 * dx * dx * c5 + c3;
+    xy = -3.0 * dx * dy * c5;
+    xz = -3.0 * dx * dz * c5;
+    yy = -3.0 * dy * dy * c5 + c3;
+    yz = -3.0 * dy * dz * c5;
+    zz = -3.0 * dz * dz * c5 + c3;
+}
+
+__global__ __launch_bounds__(64) void build_amatrix_kernel(DevAtoms a, DevBox bx, double damp,
+                                                            double *__restrict__ A, int lda) {
+    const int lane = threadIdx.x;
+    const int j0 = blockIdx.x * 128 + 2 * lane;
+    const int i0 = blockIdx.y * kARows;
+    __shared__ double sx[kARows], sy[kARows], sz[kARows], sal[kARows];
+    __shared__ int sfl[kARows];
+    if (lane < kARows) {
+        sx[lane] = a.x[i0 + lane];
+        sy[lane] = a.y[i0 + lane];
+        sz[lane] = a.z[i0 + lane];
+        sal[lane] = a.alpha[i0 + lane];
+        sfl[lane] = a.flags[i0 + lane];
+    }
+    const double2 xj = *reinterpret_cast<const double2 *>(a.x + j0);
+    const double2 yj = *reinterpret_cast<const double2 *>(a.y + j0);
+    const double2 zj = *reinterpret_cast<const double2 *>(a.z + j0);
+    const int2 flj = *reinterpret_cast<const int2 *>(a.flags + j0);
+    __syncthreads();
+
+    for (int k = 0; k < kARows; ++k) {
+        const int i = i0 + k;
+        const bool vi = sfl[k] & kValid;
+        double t0[6], t1[6];
+#pragma unroll
+        for (int u = 0; u < 6; ++u) t0[u] = t1[u] = 0.0;
+        const double dg = (sal[k] != 0.0) ? 1.0 / sal[k] : kMAXVALUE;  // thole_matrix.c:62-69
+        if (vi && (flj.x & kValid)) {
+            if (j0 == i) {
+                t0[0] = t0[3] = t0[5] = dg;
+            } else {
+                thole_tensor(bx, damp, sx[k] - xj.x, sy[k] - yj.x, sz[k] - zj.x, t0[0], t0[1], t0[2], t0[3], t0[4],
+                             t0[5]);
+            }
+        }
+        if (vi && (flj.y & kValid)) {
+            if (j0 + 1 == i) {
+                t1[0] = t1[3] = t1[5] = dg;
+            } else {
+                thole_tensor(bx, damp, sx[k] - xj.y, sy[k] - yj.y, sz[k] - zj.y, t1[0], t1[1], t1[2], t1[3], t1[4],
+                             t1[5]);
+            }
+        }
+        // t = {xx, xy, xz, yy, yz, zz}
+        double *r0 = A + (size_t)(3 * i) * lda + 3 * (size_t)j0;
+        double *r1 = r0 + lda;
+        double *r2 = r1 + lda;
+        double2 *v0 = reinterpret_cast<double2 *>(r0);
+        double2 *v1 = reinterpret_cast<double2 *>(r1);
+        double2 *v2 = reinterpret_cast<double2 *>(r2);
+        v0[0] = make_double2(t0[0], t0[1]);
+        v0[1] = make_double2(t0[2], t1[0]);
+        v0[2] = make_double2(t1[1], t1[2]);
+        v1[0] = make_double2(t0[1], t0[3]);
+        v1[1] = make_double2(t0[4], t1[1]);
+        v1[2] = make_double2(t1[3], t1[4]);
+        v2[0] = make_double2(t0[2], t0[4]);
+        v2[1] = make_double2(t0[5], t1[2]);
+        v2[2] = make_double2(t1[4], t1[5]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Dipole sweep = one pass over A (reference src/polarization/thole_iterative.c:27-59 with
+// Jacobi ordering, plus the bookkeeping of :186-252 fused into the epilogue):
+//   E_ind,i = - sum_{j != i} T_ij mu_j ;  new_mu_i = alpha_i (E_static,i + E_ind,i)
+//   mu_out  = new_mu | gamma*new + (1-gamma)*old (SOR) | ESOR weight
+// One wave per atom (its 3 rows); lanes stride the columns with 16-byte loads, three column
+// steps unrolled (9 KiB of A in flight per wave).  The wave's own 3x3 diagonal block is masked
+// out rather than subtracted afterwards (it holds 1/alpha; subtracting would cost a digit).
+// MODE_PALMO reuses the same pass: dE_i = -E_ind,i - sum_{j != i} T_ij mu_j
+// (thole_iterative.c:119-141), for every atom including non-polarizable ones.
+// grid = npad/4; block = 256 (4 waves = 4 atoms).
+// ---------------------------------------------------------------------------------------------
+enum SweepMode { kSweepJacobi = 0, kSweepPalmo = 1 };
+
+struct SweepParams {
+    double w_new;    // weight of new_mu in mu_out (1 for plain Jacobi)
+    double w_old;    // weight of old mu
+    int want_rrms;   // polar_rrms || polar_precision > 0
+    int err_slot;    // index into errmax[] for this iteration
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void sweep_kernel(const double *__restrict__ A, int lda, int npad,
+                                                     const double *__restrict__ alpha,
+                                                     const int *__restrict__ flags,
+                                                     const double *__restrict__ mu_in,
+                                                     const double *__restrict__ es,
+                                                     double *__restrict__ ef_induced,   // in for PALMO, out for JACOBI
+                                                     double *__restrict__ out,          // mu_out | ef_induced_change
+                                                     double *__restrict__ rrms,
+                                                     unsigned long long *__restrict__ errmax, SweepParams sp) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const double al = alpha[i];
+    const int fl = flags[i];
+    if (MODE == kSweepJacobi) {
+        if (al == 0.0 || !(fl & kValid)) {  // thole_iterative.c:34-39: non-polarizable rows are skipped
+            if (lane < 3) {
+                out[3 * i + lane] = 0.0;
+                ef_induced[3 * i + lane] = 0.0;
+            }
+            if (lane == 0 && sp.want_rrms) rrms[i] = 0.0;
+            return;
+        }
+    } else {
+        if (!(fl & kValid)) {
+            if (lane < 3) out[3 * i + lane] = 0.0;
+            return;
+        }
+    }
+    const double *a0 = A + (size_t)(3 * i) * lda;
+    const double *a1 = a0 + lda;
+    const double *a2 = a1 + lda;
+    const unsigned own = 3u * (unsigned)i;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    const int ncol = 3 * npad;  // multiple of 384
+    for (int c0 = 2 * lane; c0 < ncol; c0 += 384) {
+        double2 m[3], r0[3], r1[3], r2[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int c = c0 + 128 * u;
+            r0[u] = *reinterpret_cast<const double2 *>(a0 + c);
+            r1[u] = *reinterpret_cast<const double2 *>(a1 + c);
+            r2[u] = *reinterpret_cast<const double2 *>(a2 + c);
+            m[u] = *reinterpret_cast<const double2 *>(mu_in + c);
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const unsigned c = (unsigned)(c0 + 128 * u);
+            const double mx = ((c - own) < 3u) ? 0.0 : m[u].x;
+            const double my = ((c + 1u - own) < 3u) ? 0.0 : m[u].y;
+            s0 += r0[u].x * mx;
+            s0 += r0[u].y * my;
+            s1 += r1[u].x * mx;
+            s1 += r1[u].y * my;
+            s2 += r2[u].x * mx;
+            s2 += r2[u].y * my;
+        }
+    }
+    s0 = wave_sum(s0);
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (lane == 0) {
+        if (MODE == kSweepJacobi) {
+            const double e[3] = {-s0, -s1, -s2};
+            double d2 = 0.0, n2 = 0.0, emax = 0.0;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const double old = mu_in[3 * i + p];
+                const double nw = al * (es[3 * i + p] + e[p]);
+                ef_induced[3 * i + p] = e[p];
+                out[3 * i + p] = sp.w_new * nw + sp.w_old * old;
+                const double d = nw - old;
+                d2 += d * d;
+                n2 += nw * nw;
+                emax = fmax(emax, d * d);
+            }
+            if (sp.want_rrms) {
+                double rr = sqrt(d2 / n2);  // calc_dipole_rrms, thole_iterative.c:61-77
+                if (!isfinite(rr)) rr = 0.0;
+                rrms[i] = rr;
+            }
+            // are_we_done_yet (thole_iterative.c:104-113) needs max (new-old)^2: non-negative doubles
+            // order like their bit patterns, so an integer atomicMax is exact and order-independent.
+            atomicMax(errmax + sp.err_slot, (unsigned long long)__double_as_longlong(emax));
+        } else {
+            out[3 * i + 0] = -ef_induced[3 * i + 0] - s0;
+            out[3 * i + 1] = -ef_induced[3 * i + 1] - s1;
+            out[3 * i + 2] = -ef_induced[3 * i + 2] - s2;
+        }
+    }
+}
+
+// init_dipoles (thole_iterative.c:13-25): mu = alpha * E_static (* gamma unless SOR/ESOR);
+// also clears the per-call scratch (rrms, E_ind, dE_ind).
+__global__ __launch_bounds__(256) void init_dipoles_kernel(int npad, const double *__restrict__ alpha,
+                                                            const double *__restrict__ es, double scale,
+                                                            double *__restrict__ mu, double *__restrict__ ef_induced,
+                                                            double *__restrict__ ef_change,
+                                                            double *__restrict__ rrms) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npad) return;
+    const double al = alpha[i];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        mu[3 * i + p] = al * es[3 * i + p] * scale;
+        ef_induced[3 * i + p] = 0.0;
+        ef_change[3 * i + p] = 0.0;
+    }
+    rrms[i] = 0.0;
+}
+
+// Divergence fallback (thole_iterative.c:199-210): mu = alpha*E_static, dE_ind = 0.
+__global__ __launch_bounds__(256) void fallback_dipoles_kernel(int npad, const double *__restrict__ alpha,
+                                                                const double *__restrict__ es,
+                                                                double *__restrict__ mu,
+                                                                double *__restrict__ ef_change) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npad) return;
+    const double al = alpha[i];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        mu[3 * i + p] = al * es[3 * i + p];
+        ef_change[3 * i + p] = 0.0;
+    }
+}
+
+// U_pol = -1/2 sum_i mu_i . E_static,i (+ mu_i . dE_ind,i with polar_palmo)   (polar.c:107-116)
+// and observables->dipole_rrms = mean_i rrms_i (polar.c:13-28).  One block, fixed order.
+__global__ __launch_bounds__(256) void polar_energy_kernel(int n, const double *__restrict__ mu,
+                                                            const double *__restrict__ es,
+                                                            const double *__restrict__ ef_change, int palmo,
+                                                            const double *__restrict__ rrms,
+                                                            double *__restrict__ out /* [2] */) {
+    double acc = 0.0, rr = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        double e = mu[3 * i] * es[3 * i] + mu[3 * i + 1] * es[3 * i + 1] + mu[3 * i + 2] * es[3 * i + 2];
+        if (palmo)
+            e += mu[3 * i] * ef_change[3 * i] + mu[3 * i + 1] * ef_change[3 * i + 1] +
+                 mu[3 * i + 2] * ef_change[3 * i + 2];
+        acc += e;
+        const double r = rrms[i];
+        if (isfinite(r)) rr += r;
+    }
+    acc = wave_sum(acc);
+    rr = wave_sum(rr);
+    __shared__ double s[4], t[4];
+    if ((threadIdx.x & 63) == 0) {
+        s[threadIdx.x >> 6] = acc;
+        t[threadIdx.x >> 6] = rr;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[0] = -0.5 * ((s[0] + s[1]) + (s[2] + s[3]));
+        out[1] = ((t[0] + t[1]) + (t[2] + t[3])) / (double)n;
+    }
+}
+
+}  // namespace mpmc

@@ -1,0 +1,259 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP engine, called through the C ABI,
+against the CPU oracle on identical inputs, and against the reference's own golden energies.
+
+Tolerances: LJ / Ewald <= 1e-6 relative is the north-star bar; the kernels are fp64 and
+algorithm-faithful, so the tests ask for 1e-10 (summation order and libm ulps are the only
+differences).  Polarization: same bar for fixed-iteration runs (the SCF stopping rule is the
+same iteration count), and agreement of the iteration count itself in precision mode.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from mpmc_amd import engine, synth
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+FX = json.load(open(os.path.join(GOLD, "fixtures.json")))
+RTOL = 1e-10
+
+
+def load(name):
+    return dict(np.load(os.path.join(GOLD, name + ".npz")))
+
+
+def rel(a, b, floor=1.0):
+    return abs(a - b) / max(floor, abs(b))
+
+
+def run_engine(system, params, vectors=False):
+    eng = engine.Engine(len(system["charge"]))
+    try:
+        eng.load_system(system, params)
+        r = eng.energy()
+        if vectors:
+            r.update(eng.dipoles())
+            r["rank"], r["order"] = eng.ranking()
+        return r
+    finally:
+        eng.close()
+
+
+def check_energies(got, want, rtol=RTOL):
+    for k in ("rd_energy", "es_real", "es_recip", "es_self", "coulombic_energy", "polarization_energy", "energy"):
+        assert rel(got[k], want[k]) < rtol, (k, got[k], want[k])
+    assert got["polar_iterations"] == want["polar_iterations"]
+    assert got["iter_success"] == want["iter_success"]
+
+
+# ---------------------------------------------------------------------------------------------
+# golden fixtures: the reference's own numbers
+# ---------------------------------------------------------------------------------------------
+KEY = {"energy": "energy", "coulombic": "coulombic_energy", "rd": "rd_energy", "polar": "polarization_energy"}
+
+
+@pytest.mark.parametrize("name", sorted(FX))
+def test_engine_reproduces_reference_goldens(name):
+    fx = FX[name]
+    got = run_engine(load(name), fx["params"])
+    for k, want in fx["expected"].items():
+        if k in KEY:
+            assert abs(got[KEY[k]] - want) <= 0.5000001 * 10 ** (-fx["decimals"]), (name, k, got[KEY[k]], want)
+
+
+@pytest.mark.parametrize("name", ["bssp_small_10", "mof5_buch_425", "mof5_bss_429", "mof5_bssp_429",
+                                  "socmof_bssp_1228"])
+def test_engine_matches_oracle_on_fixtures(name):
+    fx = FX[name]
+    s = load(name)
+    got = run_engine(s, fx["params"], vectors=True)
+    want = oracle.energy(s, fx["params"], want_vectors=True)
+    check_energies(got, want)
+    if fx["params"].get("polarization"):
+        scale = np.abs(want["ef_static"]).max()
+        assert np.abs(got["ef_static"] - want["ef_static"]).max() <= 1e-11 * scale
+        mscale = np.abs(want["mu"]).max()
+        assert np.abs(got["mu"] - want["mu"]).max() <= 1e-10 * mscale
+        assert np.abs(got["ef_induced"] - want["ef_induced"]).max() <= 1e-10 * np.abs(want["ef_induced"]).max()
+
+
+# ---------------------------------------------------------------------------------------------
+# synthetic boxes of BASELINE.json's shapes
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [256, 1000])
+def test_lj_only(n):
+    s = synth.s_lj(n)
+    check_energies(run_engine(s, synth.FLAGS_LJ), oracle.energy(s, synth.FLAGS_LJ))
+
+
+@pytest.mark.parametrize("fh", [0, 2, 4])
+def test_lj_ewald_1024(fh):
+    s = synth.s_es(1024)
+    p = dict(synth.FLAGS_ES)
+    if fh:
+        p.update(feynman_hibbs=1, feynman_hibbs_order=fh)
+    check_energies(run_engine(s, p), oracle.energy(s, p))
+
+
+def test_ewald_options():
+    s = synth.s_es(500)
+    p = dict(temperature=100.0, ewald_alpha_set=1, ewald_alpha=0.31, ewald_kmax=5, pbc_cutoff=9.0, rd_lrc=0)
+    check_energies(run_engine(s, p), oracle.energy(s, p))
+
+
+def test_triclinic_box():
+    s = synth.s_es(432)
+    L = s["basis"][0, 0]
+    s["basis"] = np.array([[L, 0, 0], [0.2 * L, 0.95 * L, 0], [0.1 * L, -0.15 * L, 0.9 * L]])
+    p = dict(temperature=100.0, feynman_hibbs=1, feynman_hibbs_order=4)
+    check_energies(run_engine(s, p), oracle.energy(s, p))
+
+
+POLAR_VARIANTS = {
+    "jacobi10": dict(polar_max_iter=10),
+    "jacobi_sor": dict(polar_max_iter=6, polar_sor=1, polar_gamma=0.8),
+    "jacobi_esor": dict(polar_max_iter=6, polar_esor=1, polar_gamma=0.9),
+    "jacobi_palmo": dict(polar_max_iter=4, polar_palmo=1),
+    "gs": dict(polar_max_iter=4, polar_gs=1),
+    "gs_palmo_gamma": dict(polar_max_iter=4, polar_gs=1, polar_palmo=1, polar_gamma=1.03),
+    "gs_ranked": dict(polar_max_iter=4, polar_gs_ranked=1),
+    "production": dict(polar_max_iter=4, polar_gs_ranked=1, polar_palmo=1, polar_gamma=1.03, polar_wolf=1,
+                       polar_wolf_alpha=0.13),
+    "wolf0": dict(polar_max_iter=4, polar_wolf=1, polar_wolf_alpha=0.0),
+    "gs_sor": dict(polar_max_iter=5, polar_gs=1, polar_sor=1, polar_gamma=0.9),
+    "zodid": dict(polar_zodid=1),
+    "rrms": dict(polar_max_iter=5, polar_rrms=1),
+    "one_iter_ranked": dict(polar_max_iter=1, polar_gs_ranked=1, polar_palmo=1),
+}
+
+
+@pytest.mark.parametrize("variant", sorted(POLAR_VARIANTS))
+def test_polarization_variants_1024(variant):
+    s = synth.s_pol(1024)
+    p = dict(temperature=77.0, polarization=1, polar_damp=2.1304)
+    p.update(POLAR_VARIANTS[variant])
+    got = run_engine(s, p, vectors=True)
+    want = oracle.energy(s, p, want_vectors=True)
+    check_energies(got, want)
+    assert np.abs(got["mu"] - want["mu"]).max() <= 1e-10 * np.abs(want["mu"]).max()
+    assert np.abs(got["ef_induced_change"] - want["ef_induced_change"]).max() <= \
+        1e-9 * max(np.abs(want["ef_induced"]).max(), 1e-300)
+    assert rel(got["dipole_rrms"], want["dipole_rrms"], floor=1e-6) < 1e-8
+    if p.get("polar_gs_ranked"):
+        assert np.array_equal(got["rank"], want["rank_metric"])
+        assert np.array_equal(got["order"], want["ranked_array"])
+
+
+@pytest.mark.parametrize("gs", [0, 1])
+def test_precision_mode(gs):
+    """polar_precision stopping rule (thole_iterative.c:104-113): same iteration count, same dipoles."""
+    s = synth.s_pol(640)
+    p = dict(temperature=77.0, polarization=1, polar_damp=2.1304, polar_max_iter=0, polar_precision=1e-6,
+             polar_gs=gs)
+    got = run_engine(s, p, vectors=True)
+    want = oracle.energy(s, p, want_vectors=True)
+    check_energies(got, want)
+    assert got["polar_iterations"] > 2
+    assert rel(got["dipole_rrms"], want["dipole_rrms"], floor=1e-12) < 1e-6
+
+
+def test_scf_divergence_sets_failure_flag():
+    """A configuration whose SCF diverges must come back with iter_success = 1 and the
+    alpha*E fallback dipoles (thole_iterative.c:199-210), not with an error."""
+    s = synth.s_pol(320, spacing=3.0)
+    s["alpha"] = s["alpha"] * 40.0  # polarization catastrophe
+    p = dict(temperature=77.0, polarization=1, polar_damp=2.1304, polar_max_iter=0, polar_precision=1e-8)
+    got = run_engine(s, p, vectors=True)
+    want = oracle.energy(s, p, want_vectors=True)
+    assert want["iter_success"] == 1 and got["iter_success"] == 1
+    assert got["polar_iterations"] == want["polar_iterations"] == 128
+    assert rel(got["polarization_energy"], want["polarization_energy"]) < 1e-9
+
+
+def test_amatrix_matches_oracle():
+    s = synth.s_pol(320)
+    p = dict(synth.FLAGS_POL_JACOBI)
+    eng = engine.Engine(320)
+    eng.load_system(s, p)
+    eng.energy()
+    A = eng.amatrix()
+    eng.close()
+    want = oracle.energy(s, p, want_A=True)["A_matrix"]
+    assert np.array_equal(A, A.T)
+    off = ~np.kron(np.eye(320, dtype=bool), np.ones((3, 3), dtype=bool))
+    assert np.abs(A - want)[off].max() <= 1e-13 * np.abs(want[off]).max()
+    assert np.allclose(np.diag(A), np.diag(want), rtol=1e-15)
+
+
+def test_frozen_framework_and_update_atoms():
+    """Moving one molecule through update_atoms == fresh upload; reject path restores the energy."""
+    s = load("socmof_bssp_1228")
+    p = FX["socmof_bssp_1228"]["params"]
+    eng = engine.Engine(1228)
+    eng.load_system(s, p)
+    e0 = eng.energy()
+    first = 1228 - 5
+    newpos = s["pos"][first:] + np.array([0.3, -0.2, 0.1])
+    eng.update_atoms(first, newpos)
+    e1 = eng.energy()
+    s2 = dict(s)
+    s2["pos"] = s["pos"].copy()
+    s2["pos"][first:] = newpos
+    want = oracle.energy(s2, p)
+    check_energies(e1, want)
+    eng.update_atoms(first, s["pos"][first:])
+    e2 = eng.energy()
+    assert e2["energy"] == e0["energy"]  # bitwise: deterministic reductions
+    eng.close()
+
+
+def test_ragged_sizes_and_padding():
+    """n not a multiple of the tile sizes, down to a single molecule."""
+    for n in (5, 63, 65, 129, 257):
+        s = synth.s_pol(n)
+        p = dict(temperature=77.0, polarization=1, polar_damp=2.1304, polar_max_iter=3, polar_gs=1)
+        check_energies(run_engine(s, p), oracle.energy(s, p))
+
+
+def test_error_paths():
+    eng = engine.Engine(64)
+    with pytest.raises(engine.EngineError):
+        eng.energy()  # nothing uploaded
+    with pytest.raises(engine.EngineError):
+        eng.set_params(polarization=1, polar_damp=2.1304, polar_precision=1e-5, polar_max_iter=10)
+    with pytest.raises(engine.EngineError):
+        eng.set_box(np.zeros((3, 3)))
+    s = synth.s_lj(100)
+    with pytest.raises(engine.EngineError):
+        eng.upload(s)  # exceeds max_atoms
+    eng.close()
+
+
+def test_timings_available():
+    s = synth.s_pol(1024)
+    eng = engine.Engine(1024)
+    eng.load_system(s, synth.FLAGS_POL_JACOBI)
+    eng.energy()
+    t = eng.timings()
+    eng.close()
+    assert t["sweep_count"] == 10 and t["sweep_ms"] > 0 and t["amatrix_ms"] > 0 and t["total_ms"] > 0
+
+
+def test_rccl_single_rank_allreduce():
+    import ctypes as C
+
+    lib = engine.load()
+    eng = engine.Engine(64)
+    uid = (C.c_ubyte * 128)()
+    assert lib.mpmc_hip_comm_unique_id(uid) == 0, lib.mpmc_hip_last_error()
+    comm = C.c_void_p()
+    assert lib.mpmc_hip_comm_create(C.byref(comm), eng.ctx, 1, 0, uid) == 0, lib.mpmc_hip_last_error()
+    v = np.arange(8, dtype=np.float64)
+    assert lib.mpmc_hip_allreduce_observables(comm, v.ctypes.data, 8) == 0, lib.mpmc_hip_last_error()
+    assert np.array_equal(v, np.arange(8, dtype=np.float64))
+    lib.mpmc_hip_comm_destroy(comm)
+    eng.close()
