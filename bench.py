@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""bench.py -- MC steps/s of the polarizable 4096-atom box on N x MI355X (one walker per GPU).
+
+One "step" = one single-molecule displacement (translate + rotate, reference
+src/mc/mc_moves.c:378-488) + one FULL energy() on the device through the C ABI + Metropolis
+(reference src/mc/mc.c:294-353), exactly what the reference does per step.  Workload: the
+4096-atom PCN-61 cell + 416 BSSP H2 of tests/golden/pcn61_bssp_4096.npz with the flags of the
+reference's sample_configs_gpu/3_PCN61/iter.inp run as NVT (Jacobi x4, cutoff 8 A, FH 4th order)
+-- BASELINE.json configs[3]; `--workload` selects the synthetic boxes instead.
+
+Walkers are independent: rank r runs its own chain with seed+r on GPU r; the only
+collective is the sum of a small observable vector every `corrtime` steps (RCCL over xGMI via
+torch.distributed, backend "nccl").  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def load_workload(name):
+    from mpmc_amd import synth
+
+    if name == "pcn61_4096":
+        s = dict(np.load(os.path.join(ROOT, "tests", "golden", "pcn61_bssp_4096.npz")))
+        flags = dict(temperature=77.0, polarization=1, polar_damp=2.1304, polar_max_iter=4, pbc_cutoff=8.0,
+                     feynman_hibbs=1, feynman_hibbs_order=4)
+        label = "PCN-61 cell + 416 BSSP H2, 4096 atoms (2016 frozen), polarizable, Jacobi x4, rc 8 A, FH4"
+        return s, flags, label
+    kind, n = name.rsplit("_", 1)
+    n = int(n)
+    if kind == "spol":
+        return synth.s_pol(n), dict(synth.FLAGS_POL_JACOBI), "S-POL(%d): BSSP H2 box, Jacobi x10, FH4" % n
+    if kind == "spolprod":
+        return synth.s_pol(n), dict(synth.FLAGS_POL_PRODUCTION), "S-POL(%d): production flags (wolf, GS-ranked, Palmo)" % n
+    if kind == "ses":
+        return synth.s_es(n), dict(synth.FLAGS_ES), "S-ES(%d): LJ + Ewald dimers" % n
+    if kind == "slj":
+        return synth.s_lj(n), dict(synth.FLAGS_LJ), "S-LJ(%d): LJ only" % n
+    raise SystemExit("unknown workload " + name)
+
+
+class Walker:
+    """Minimal NVT Markov chain around the engine (host control; the energy is the hot path)."""
+
+    def __init__(self, eng, system, flags, seed, move_factor=0.01, rot_factor=0.01):
+        self.eng = eng
+        self.pos = np.array(system["pos"], dtype=np.float64)
+        self.mass = np.asarray(system["mass"], dtype=np.float64)
+        mol = np.asarray(system["molecule"])
+        frozen = np.asarray(system["frozen"])
+        starts = np.flatnonzero(np.r_[True, mol[1:] != mol[:-1]])
+        ends = np.r_[starts[1:], len(mol)]
+        self.movable = [(int(a), int(b)) for a, b in zip(starts, ends) if not frozen[a]]
+        self.rng = np.random.default_rng(seed)
+        self.T = flags["temperature"]
+        self.move_factor = move_factor
+        self.rot_factor = rot_factor
+        self.cutoff = None
+        self.energy = None
+        self.accepted = 0
+
+    def initial(self):
+        r = self.eng.energy()
+        self.energy = r["energy"]
+        self.cutoff = r["cutoff"]
+        return r
+
+    def step(self):
+        a, b = self.movable[self.rng.integers(len(self.movable))]
+        old = self.pos[a:b].copy()
+        m = self.mass[a:b]
+        com = (m[:, None] * old).sum(0) / m.sum() if m.sum() > 0 else old.mean(0)
+        # translate: +-scale*U*cutoff per axis (mc_moves.c:378-398)
+        t = self.move_factor * self.rng.random(3) * self.cutoff * np.where(self.rng.random(3) < 0.5, -1.0, 1.0)
+        # rotate about a random axis by U*360*scale degrees (mc_moves.c:402-465)
+        ax = self.rng.random(3) - 0.5
+        ax /= np.linalg.norm(ax)
+        ang = np.deg2rad(self.rng.random() * 360.0 * self.rot_factor)
+        K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+        R = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * (K @ K)
+        new = (old - com) @ R.T + com + t
+        self.eng.update_atoms(a, new)
+        r = self.eng.energy()
+        e_new = r["energy"]
+        ok = np.isfinite(e_new) and r["iter_success"] == 0 and \
+            self.rng.random() < np.exp(min(0.0, -(e_new - self.energy) / self.T))
+        if ok:
+            self.pos[a:b] = new
+            self.energy = e_new
+            self.accepted += 1
+        else:
+            self.eng.update_atoms(a, old)  # restore(); the next energy() recomputes everything anyway
+        return r
+
+
+def cpu_baseline(system, flags, budget_s=20.0):
+    """The CPU oracle (a port of the reference path) timed on this host, 1 core, bounded sample."""
+    from oracle import oracle
+
+    t0 = time.perf_counter()
+    nstep = 0
+    pos = np.array(system["pos"])
+    s = dict(system)
+    rng = np.random.default_rng(7)
+    while True:
+        s["pos"] = pos + 0.0
+        s["pos"][-1] += 0.01 * rng.random(3)
+        oracle.energy(s, flags)
+        nstep += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or nstep >= 50:
+            break
+    return dict(value=nstep / el, unit="MC steps/s", cores=1, kind="port",
+                sample="%d full energy() evaluations of the same workload by oracle/ (C restatement of the "
+                       "reference CPU path, gcc -O3, 1 thread), %.1f s" % (nstep, el))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="pcn61_4096")
+    ap.add_argument("--corrtime", type=int, default=10)
+    ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+
+    from mpmc_amd import engine
+
+    system, flags, label = load_workload(args.workload)
+    n = len(system["charge"])
+    eng = engine.Engine(n, device=local_rank)
+    eng.load_system(system, flags)
+    walker = Walker(eng, system, flags, seed=args.seed + rank)
+    walker.initial()
+    obs = torch.zeros(8, dtype=torch.float64, device=dev)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    def run(nsteps, collect):
+        acc = dict(sweep_ms=0.0, sweep_count=0, amatrix_ms=0.0, pair_ms=0.0, recip_ms=0.0, field_ms=0.0,
+                   palmo_ms=0.0, other_ms=0.0, total_ms=0.0)
+        esum = np.zeros(8)
+        for k in range(1, nsteps + 1):
+            r = walker.step()
+            esum += [1.0, walker.energy, walker.energy ** 2, r["rd_energy"], r["coulombic_energy"],
+                     r["polarization_energy"], r["polar_iterations"], 0.0]
+            if collect:
+                t = eng.timings()
+                for key in acc:
+                    acc[key] += t[key]
+            if k % args.corrtime == 0:
+                # walker averaging every corrtime (reference mc.c:417-432: MPI_Gather of observables)
+                obs.copy_(torch.from_numpy(esum))
+                if dist is not None:
+                    dist.all_reduce(obs)
+                esum[:] = 0.0
+        return acc
+
+    run(args.warmup, False)
+    sync()
+    t0 = time.perf_counter()
+    acc = run(args.steps, True)
+    sync()
+    elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+
+    if rank == 0:
+        value = world * args.steps / elapsed
+        sweep_avg_ms = acc["sweep_ms"] / max(1, acc["sweep_count"])
+        npad = (n + 127) // 128 * 128
+        # algorithmic bytes of one sweep launch: A read once (3N x 3N fp64) + mu, E_static in, mu, E_ind out
+        sweep_bytes = (3.0 * n) ** 2 * 8 + 5 * 3 * n * 8
+        achieved = sweep_bytes / (sweep_avg_ms * 1e-3) / 1e9 if sweep_avg_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "sweep_pmc_latest.json")
+        if os.path.exists(pmc) and args.workload == "pcn61_4096":
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "MC steps/sec (polarizable, 4096 atoms)",
+            "value": value,
+            "unit": "MC steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic" if args.workload != "pcn61_4096" else
+                    "reference sample geometry (PCN-61 cell carved from sample_configs_gpu/3_PCN61/input.pdb), "
+                    "random MC moves",
+            "config": {"workload": label, "n_atoms": n, "walkers": world, "corrtime": args.corrtime,
+                       "parallelism": "%d independent walkers, 1 per GPU" % world},
+            "roofline": {"kernel": "sweep_kernel<Jacobi> (Thole field / dipole sweep)", "bound": "hbm",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "avg_launch_ms": sweep_avg_ms, "launches": acc["sweep_count"],
+                         "algorithmic_bytes_per_launch": sweep_bytes},
+            "device_ms_per_step": {k: acc[k] / args.steps for k in
+                                   ("pair_ms", "recip_ms", "field_ms", "amatrix_ms", "sweep_ms", "palmo_ms",
+                                    "other_ms", "total_ms")},
+            "acceptance": walker.accepted / float(args.steps + args.warmup),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(system, flags)
+        print(json.dumps(out))
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
