@@ -198,9 +198,11 @@ def main():
     if rank == 0:
         value = world * args.steps / elapsed
         sweep_avg_ms = acc["sweep_ms"] / max(1, acc["sweep_count"])
-        npad = (n + 127) // 128 * 128
-        # algorithmic bytes of one sweep launch: A read once (3N x 3N fp64) + mu, E_static in, mu, E_ind out
-        sweep_bytes = (3.0 * n) ** 2 * 8 + 5 * 3 * n * 8
+        # algorithmic bytes of one sweep launch: the rows of A that belong to polarizable atoms
+        # (rows of alpha = 0 sites are skipped, as in the reference's contract_dipoles) x all 3N
+        # columns, fp64, read once; + mu, E_static in and mu, E_ind out
+        n_pol = int(np.count_nonzero(np.asarray(system["alpha"]) != 0.0))
+        sweep_bytes = (3.0 * n_pol) * (3.0 * n) * 8 + 5 * 3 * n * 8
         achieved = sweep_bytes / (sweep_avg_ms * 1e-3) / 1e9 if sweep_avg_ms > 0 else 0.0
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "sweep_pmc_latest.json")
@@ -224,7 +226,7 @@ def main():
             "data": "synthetic" if args.workload != "pcn61_4096" else
                     "reference sample geometry (PCN-61 cell carved from sample_configs_gpu/3_PCN61/input.pdb), "
                     "random MC moves",
-            "config": {"workload": label, "n_atoms": n, "walkers": world, "corrtime": args.corrtime,
+            "config": {"workload": label, "n_atoms": n, "n_polarizable": n_pol, "walkers": world, "corrtime": args.corrtime,
                        "parallelism": "%d independent walkers, 1 per GPU" % world},
             "roofline": {"kernel": "sweep_kernel<Jacobi> (Thole field / dipole sweep)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
