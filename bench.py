@@ -198,11 +198,11 @@ def main():
     if rank == 0:
         value = world * args.steps / elapsed
         sweep_avg_ms = acc["sweep_ms"] / max(1, acc["sweep_count"])
-        # algorithmic bytes of one sweep launch: the rows of A that belong to polarizable atoms
-        # (rows of alpha = 0 sites are skipped, as in the reference's contract_dipoles) x all 3N
-        # columns, fp64, read once; + mu, E_static in and mu, E_ind out
+        # algorithmic bytes of one sweep launch: the polarizable block of A, (3 n_pol)^2 fp64, read
+        # once (sites with alpha = 0 carry no dipole: neither their rows nor their columns are
+        # needed, cf. contract_dipoles) + mu, E_static in and mu, E_ind out
         n_pol = int(np.count_nonzero(np.asarray(system["alpha"]) != 0.0))
-        sweep_bytes = (3.0 * n_pol) * (3.0 * n) * 8 + 5 * 3 * n * 8
+        sweep_bytes = (3.0 * n_pol) ** 2 * 8 + 5 * 3 * n_pol * 8
         achieved = sweep_bytes / (sweep_avg_ms * 1e-3) / 1e9 if sweep_avg_ms > 0 else 0.0
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "sweep_pmc_latest.json")

@@ -107,6 +107,13 @@ int mpmc_hip_device_count(void);
 int mpmc_hip_create(mpmc_hip_ctx **ctx, int device, int max_atoms);
 void mpmc_hip_destroy(mpmc_hip_ctx *ctx);
 
+/* Engine knobs that do not change results, for A/B measurement:
+ *   "incremental_amatrix" (default 1): after mpmc_hip_update_atoms() rewrite only the moved atoms'
+ *                          block-rows/-columns of the resident A matrix instead of rebuilding it;
+ *   "overlap_streams"     (default 1): run the LJ/Ewald kernels on a second HIP stream beside the
+ *                          polarization chain. */
+int mpmc_hip_set_option(mpmc_hip_ctx *ctx, const char *name, int value);
+
 void mpmc_hip_default_params(mpmc_hip_params *p);
 int mpmc_hip_set_params(mpmc_hip_ctx *ctx, const mpmc_hip_params *p);
 

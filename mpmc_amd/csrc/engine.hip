@@ -63,6 +63,8 @@ extern "C" int mpmc_hip_device_count(void) {
 // ------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------
+constexpr int kMaxDirty = 64;  // more moved atoms than this => full A rebuild
+
 enum TimeClass { T_PAIR = 0, T_RECIP, T_FIELD, T_AMAT, T_SWEEP, T_PALMO, T_OTHER, T_NCLASS };
 
 struct TimeRec {
@@ -83,12 +85,24 @@ enum ResSlot {
     R_COUNT = 16
 };
 
-// scratch for the permuted (ranked) Gauss-Seidel problem
-struct PermScratch {
+// A "sweep view" = the polarizable atoms, compacted, in the order the SCF sweep visits them.
+// View 0: atom order (Jacobi, polar_gs and the first polar_gs_ranked sweep); view 1: ranked order.
+// Non-polarizable sites have mu = 0 and their rows are skipped by the reference
+// (thole_iterative.c:34-39), so neither their rows nor their columns of A are ever needed by the
+// solver: the device matrix is (3 nv)^2 instead of (3 N)^2.
+struct SweepView {
+    int nv = 0, nvpad = 0, cap = 0;
+    int *d_idx = nullptr;  // atom index of view slot k
     double *px = nullptr, *py = nullptr, *pz = nullptr, *palpha = nullptr;
     int *pflags = nullptr;
-    double *es = nullptr, *mu_old = nullptr, *mu_new = nullptr, *y = nullptr;
-    int cap = 0;
+    double *A = nullptr;
+    size_t Acap = 0;  // doubles
+    bool A_valid = false;  // A matches the configuration as of the last energy() (minus `dirty` atoms)
+    int *d_dirty = nullptr;
+    std::vector<int> slot_of_atom;  // atom index -> view slot, -1 if not in the view
+    double *es = nullptr, *mu0 = nullptr, *mu1 = nullptr, *munew = nullptr, *y = nullptr, *efind = nullptr,
+           *efchg = nullptr, *rrms = nullptr;
+    std::vector<int> h_idx;
 };
 
 struct mpmc_hip_ctx {
@@ -100,16 +114,18 @@ struct mpmc_hip_ctx {
     double *d_x = nullptr, *d_y = nullptr, *d_z = nullptr, *d_q = nullptr, *d_alpha = nullptr, *d_eps = nullptr,
            *d_sig = nullptr, *d_molmass = nullptr;
     int *d_mol = nullptr, *d_flags = nullptr;
-    // polarization state
-    double *d_A = nullptr;
-    size_t A_capacity = 0;  // in doubles
-    double *d_Aperm = nullptr;
-    size_t Aperm_capacity = 0;
-    double *d_es = nullptr, *d_mu0 = nullptr, *d_mu1 = nullptr, *d_efind = nullptr, *d_efchg = nullptr,
-           *d_rrms = nullptr, *d_rank = nullptr, *d_gsy = nullptr, *d_munew = nullptr;
-    int *d_perm = nullptr;
+    // polarization state: full-size per-atom vectors (atom order) + the two sweep views
+    SweepView view[2];
+    double *d_es = nullptr, *d_mu = nullptr, *d_efind = nullptr, *d_efchg = nullptr, *d_rank = nullptr,
+           *d_tmp3 = nullptr;
     unsigned long long *d_errmax = nullptr;
-    double *d_mu_final = nullptr;  // points at d_mu0 or d_mu1 after the last energy()
+    bool have_polar_result = false;
+    std::vector<int> dirty_atoms;   // atoms moved by update_atoms() since the last energy()
+    bool all_dirty = true;
+    int opt_incremental = 1, opt_overlap = 1;
+    int *h_dirty = nullptr;         // pinned staging for dirty slots
+    hipStream_t stream2 = nullptr;  // pair / reciprocal kernels overlap the polarization chain
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // scratch
     double *d_pairpart = nullptr;   // [ntile*ntile][4]
     double *d_fieldpart = nullptr;  // [nchunk][3][npad]
@@ -121,8 +137,7 @@ struct mpmc_hip_ctx {
     unsigned long long *h_err = nullptr;  // pinned, 1 word
     double *h_rank = nullptr;             // pinned, max_npad
     int *h_perm = nullptr;                // pinned, max_npad
-    std::vector<int> perm;                // final sweep order (atoms)
-    PermScratch ps;
+    std::vector<int> perm;                // final sweep order (all atoms, as ranked_array)
     // host state
     mpmc_hip_params par;
     bool have_params = false, have_box = false, have_atoms = false;
@@ -172,24 +187,37 @@ static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 struct ScopedTimer {
     mpmc_hip_ctx *c;
+    hipStream_t s;
     TimeRec r;
     bool on;
-    ScopedTimer(mpmc_hip_ctx *ctx, int cls) : c(ctx), on(false) {
+    ScopedTimer(mpmc_hip_ctx *ctx, int cls, hipStream_t st = nullptr) : c(ctx), s(st ? st : ctx->stream), on(false) {
         if (c->ev_next + 2 <= c->ev_pool.size()) {
             r.cls = cls;
             r.a = c->ev_pool[c->ev_next++];
             r.b = c->ev_pool[c->ev_next++];
-            hipEventRecord(r.a, c->stream);
+            hipEventRecord(r.a, s);
             on = true;
         }
     }
     ~ScopedTimer() {
         if (on) {
-            hipEventRecord(r.b, c->stream);
+            hipEventRecord(r.b, s);
             c->recs.push_back(r);
         }
     }
 };
+
+extern "C" int mpmc_hip_set_option(mpmc_hip_ctx *c, const char *name, int value) {
+    if (!c || !name) return fail("MPMC_HIP: set_option: null argument");
+    if (!strcmp(name, "incremental_amatrix")) {
+        c->opt_incremental = value;
+        c->all_dirty = true;
+    } else if (!strcmp(name, "overlap_streams"))
+        c->opt_overlap = value;
+    else
+        return fail("MPMC_HIP: set_option: unknown option '%s'", name);
+    return 0;
+}
 
 extern "C" void mpmc_hip_default_params(mpmc_hip_params *p) {
     memset(p, 0, sizeof(*p));
@@ -219,6 +247,9 @@ extern "C" int mpmc_hip_create(mpmc_hip_ctx **out, int device, int max_atoms) {
     mpmc_hip_default_params(&c->par);
     const size_t np = (size_t)c->max_npad;
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
 #define DALLOC(ptr, count, type) HIPCHK(hipMalloc((void **)&(ptr), (count) * sizeof(type)))
     DALLOC(c->d_x, np, double);
     DALLOC(c->d_y, np, double);
@@ -231,16 +262,30 @@ extern "C" int mpmc_hip_create(mpmc_hip_ctx **out, int device, int max_atoms) {
     DALLOC(c->d_mol, np, int);
     DALLOC(c->d_flags, np, int);
     DALLOC(c->d_es, 3 * np, double);
-    DALLOC(c->d_mu0, 3 * np, double);
-    DALLOC(c->d_mu1, 3 * np, double);
+    DALLOC(c->d_mu, 3 * np, double);
     DALLOC(c->d_efind, 3 * np, double);
     DALLOC(c->d_efchg, 3 * np, double);
-    DALLOC(c->d_gsy, 3 * np, double);
-    DALLOC(c->d_munew, 3 * np, double);
-    DALLOC(c->d_rrms, np, double);
+    DALLOC(c->d_tmp3, 3 * np, double);
     DALLOC(c->d_rank, np, double);
-    DALLOC(c->d_perm, np, int);
     DALLOC(c->d_errmax, 256, unsigned long long);
+    for (SweepView &v : c->view) {
+        v.cap = (int)np;
+        DALLOC(v.d_idx, np, int);
+        DALLOC(v.d_dirty, kMaxDirty, int);
+        DALLOC(v.px, np, double);
+        DALLOC(v.py, np, double);
+        DALLOC(v.pz, np, double);
+        DALLOC(v.palpha, np, double);
+        DALLOC(v.pflags, np, int);
+        DALLOC(v.es, 3 * np, double);
+        DALLOC(v.mu0, 3 * np, double);
+        DALLOC(v.mu1, 3 * np, double);
+        DALLOC(v.munew, 3 * np, double);
+        DALLOC(v.y, 3 * np, double);
+        DALLOC(v.efind, 3 * np, double);
+        DALLOC(v.efchg, 3 * np, double);
+        DALLOC(v.rrms, np, double);
+    }
     const size_t ntile = np / 64;
     DALLOC(c->d_pairpart, ntile * ntile * kPairChannels, double);
     const size_t nchunk_max = std::max<size_t>(1, np / 64);
@@ -251,6 +296,7 @@ extern "C" int mpmc_hip_create(mpmc_hip_ctx **out, int device, int max_atoms) {
     HIPCHK(hipHostMalloc((void **)&c->h_err, sizeof(unsigned long long), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&c->h_rank, np * sizeof(double), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&c->h_perm, np * sizeof(int), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&c->h_dirty, kMaxDirty * sizeof(int), hipHostMallocDefault));
     c->ev_pool.resize(2 * 512);
     for (auto &e : c->ev_pool) HIPCHK(hipEventCreate(&e));
     HIPCHK(hipEventCreate(&c->ev_first));
@@ -265,20 +311,27 @@ extern "C" void mpmc_hip_destroy(mpmc_hip_ctx *c) {
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
-    void *dptrs[] = {c->d_x,     c->d_y,     c->d_z,      c->d_q,         c->d_alpha,    c->d_eps,  c->d_sig,
-                     c->d_molmass, c->d_mol, c->d_flags,  c->d_A,         c->d_Aperm,    c->d_es,   c->d_mu0,
-                     c->d_mu1,   c->d_efind, c->d_efchg,  c->d_rrms,      c->d_rank,     c->d_gsy,  c->d_munew,
-                     c->d_perm,  c->d_errmax, c->d_pairpart, c->d_fieldpart, c->d_perk, c->d_kvec, c->d_res};
+    if (c->stream2) hipStreamSynchronize(c->stream2);
+    void *dptrs[] = {c->d_x,   c->d_y,     c->d_z,     c->d_q,    c->d_alpha, c->d_eps,      c->d_sig,
+                     c->d_molmass, c->d_mol, c->d_flags, c->d_es, c->d_mu,    c->d_efind,    c->d_efchg,
+                     c->d_tmp3, c->d_rank, c->d_errmax, c->d_pairpart, c->d_fieldpart, c->d_perk, c->d_kvec,
+                     c->d_res};
     for (void *p : dptrs)
         if (p) hipFree(p);
-    void *pptrs[] = {c->ps.px, c->ps.py, c->ps.pz, c->ps.palpha, c->ps.pflags, c->ps.es, c->ps.mu_old, c->ps.mu_new,
-                     c->ps.y};
-    for (void *p : pptrs)
-        if (p) hipFree(p);
+    for (SweepView &v : c->view) {
+        void *vp[] = {v.d_idx, v.d_dirty, v.px, v.py, v.pz, v.palpha, v.pflags, v.A,    v.es,
+                      v.mu0,   v.mu1, v.munew, v.y, v.efind, v.efchg, v.rrms};
+        for (void *p : vp)
+            if (p) hipFree(p);
+    }
+    if (c->stream2) hipStreamDestroy(c->stream2);
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
+    if (c->ev_join) hipEventDestroy(c->ev_join);
     if (c->h_res) hipHostFree(c->h_res);
     if (c->h_err) hipHostFree(c->h_err);
     if (c->h_rank) hipHostFree(c->h_rank);
     if (c->h_perm) hipHostFree(c->h_perm);
+    if (c->h_dirty) hipHostFree(c->h_dirty);
     for (auto &e : c->ev_pool) hipEventDestroy(e);
     if (c->ev_first) hipEventDestroy(c->ev_first);
     if (c->ev_last) hipEventDestroy(c->ev_last);
@@ -304,6 +357,7 @@ extern "C" int mpmc_hip_set_params(mpmc_hip_ctx *c, const mpmc_hip_params *p) {
         if (p->polar_gamma < 0.0) return fail("MPMC_HIP: invalid Pre-cond/SOR/ESOR gamma set");
         if (p->polar_ewald) return fail("MPMC_HIP: polar_ewald static field is not implemented yet");
     }
+    if (p->polar_damp != c->par.polar_damp) c->all_dirty = true;
     c->par = *p;
     c->have_params = true;
     c->kvec_valid = false;
@@ -354,6 +408,7 @@ extern "C" int mpmc_hip_set_box(mpmc_hip_ctx *c, const double basis[9], double p
     c->have_box = true;
     c->kvec_valid = false;
     c->lrc_valid = false;
+    c->all_dirty = true;
     return 0;
 }
 
@@ -407,9 +462,23 @@ extern "C" int mpmc_hip_upload(mpmc_hip_ctx *c, int n, const double *x, const do
     c->n = n;
     c->npad = npad;
     c->have_atoms = true;
+    c->have_polar_result = false;
     c->lrc_valid = false;
     c->perm.assign(n, 0);
     std::iota(c->perm.begin(), c->perm.end(), 0);
+    // view 0: polarizable atoms in atom order
+    SweepView &v0 = c->view[0];
+    v0.h_idx.clear();
+    for (int i = 0; i < n; ++i)
+        if (polarizability[i] != 0.0) v0.h_idx.push_back(i);
+    v0.nv = (int)v0.h_idx.size();
+    v0.nvpad = std::max(128, round_up(v0.nv, 128));
+    v0.slot_of_atom.assign(n, -1);
+    for (int k = 0; k < v0.nv; ++k) v0.slot_of_atom[v0.h_idx[k]] = k;
+    c->all_dirty = true;
+    c->dirty_atoms.clear();
+    c->view[0].A_valid = c->view[1].A_valid = false;
+    if (v0.nv > 0) HIPCHK(hipMemcpy(v0.d_idx, v0.h_idx.data(), v0.nv * sizeof(int), hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -426,6 +495,12 @@ extern "C" int mpmc_hip_update_atoms(mpmc_hip_ctx *c, int first, int count, cons
     HIPCHK(hipMemcpyAsync(c->d_z + first, z, b, hipMemcpyHostToDevice, c->stream));
     // pageable sources: make sure the copies are complete before the caller reuses its buffers
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (!c->all_dirty) {
+        if ((int)c->dirty_atoms.size() + count > 4 * kMaxDirty)
+            c->all_dirty = true;
+        else
+            for (int i = 0; i < count; ++i) c->dirty_atoms.push_back(first + i);
+    }
     return 0;
 }
 
@@ -470,21 +545,14 @@ static int build_kvectors(mpmc_hip_ctx *c) {
     return 0;
 }
 
-static int ensure_amatrix(mpmc_hip_ctx *c, bool need_perm) {
-    const size_t need = (size_t)(3 * (size_t)c->npad) * (3 * (size_t)c->npad);
-    if (c->A_capacity < need) {
-        if (c->d_A) hipFree(c->d_A);
-        c->d_A = nullptr;
-        c->A_capacity = 0;
-        HIPCHK(hipMalloc((void **)&c->d_A, need * sizeof(double)));
-        c->A_capacity = need;
-    }
-    if (need_perm && c->Aperm_capacity < need) {
-        if (c->d_Aperm) hipFree(c->d_Aperm);
-        c->d_Aperm = nullptr;
-        c->Aperm_capacity = 0;
-        HIPCHK(hipMalloc((void **)&c->d_Aperm, need * sizeof(double)));
-        c->Aperm_capacity = need;
+static int ensure_view_matrix(SweepView &v) {
+    const size_t need = (size_t)(3 * (size_t)v.nvpad) * (3 * (size_t)v.nvpad);
+    if (v.Acap < need) {
+        if (v.A) hipFree(v.A);
+        v.A = nullptr;
+        v.Acap = 0;
+        HIPCHK(hipMalloc((void **)&v.A, need * sizeof(double)));
+        v.Acap = need;
     }
     return 0;
 }
@@ -513,31 +581,32 @@ extern "C" int mpmc_hip_energy(mpmc_hip_ctx *c, mpmc_hip_result *out) {
     const int ntile = c->npad / 64;
     int polar_iterations = 0, iter_success = 0;
 
-    // ---- polarization first, as energy.c:108-129 does
-    const bool do_polar = !P.rd_only && P.polarization;
-    if (do_polar) {
-        if (run_polarization(c, a, bx, &polar_iterations, &iter_success)) return -1;
-    } else {
-        HIPCHK(hipMemsetAsync(c->d_res + R_UPOL, 0, 2 * sizeof(double), c->stream));
+    // ---- fork: LJ / Ewald kernels (fp64-VALU bound) run on stream2 while the polarization chain
+    // (HBM bound) runs on the main stream -- the device-side analogue of the reference starting its
+    // polarization worker before the other energy terms (energy.c:108-129, :181-186).
+    hipStream_t sb = c->opt_overlap ? c->stream2 : c->stream;
+    if (c->opt_overlap) {
+        hipEventRecord(c->ev_fork, c->stream);
+        hipStreamWaitEvent(sb, c->ev_fork, 0);
     }
 
     // ---- LJ long-range correction: parameters + volume only => cached (lj.c:56-107)
     if (P.rd_lrc) {
         if (!c->lrc_valid) {
-            ScopedTimer t(c, T_OTHER);
-            hipLaunchKernelGGL(lj_lrc_kernel, dim3(ntile, ntile), dim3(64), 0, c->stream, a, bx, c->d_pairpart);
-            hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, c->stream, c->d_pairpart, ntile * ntile, 1,
+            ScopedTimer t(c, T_OTHER, sb);
+            hipLaunchKernelGGL(lj_lrc_kernel, dim3(ntile, ntile), dim3(64), 0, sb, a, bx, c->d_pairpart);
+            hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, sb, c->d_pairpart, ntile * ntile, 1,
                                c->d_res + R_LRC);
             c->lrc_valid = true;
         }
     } else {
-        HIPCHK(hipMemsetAsync(c->d_res + R_LRC, 0, sizeof(double), c->stream));
+        HIPCHK(hipMemsetAsync(c->d_res + R_LRC, 0, sizeof(double), sb));
         c->lrc_valid = false;
     }
 
     // ---- fused pair kernel: LJ(+FH) and real-space Ewald(+FH, + intra-molecular screening)
     {
-        ScopedTimer t(c, T_PAIR);
+        ScopedTimer t(c, T_PAIR, sb);
         PairParams pp;
         pp.ewald_alpha = c->ewald_alpha;
         pp.temperature = P.temperature;
@@ -545,35 +614,48 @@ extern "C" int mpmc_hip_energy(mpmc_hip_ctx *c, mpmc_hip_result *out) {
         pp.fh_order = P.feynman_hibbs ? P.feynman_hibbs_order : 0;
         const dim3 grid(ntile, ntile), block(64);
         if (pp.fh_order == 0)
-            hipLaunchKernelGGL(pair_rd_es_kernel<0>, grid, block, 0, c->stream, a, bx, pp, c->d_pairpart);
+            hipLaunchKernelGGL(pair_rd_es_kernel<0>, grid, block, 0, sb, a, bx, pp, c->d_pairpart);
         else if (pp.fh_order == 2)
-            hipLaunchKernelGGL(pair_rd_es_kernel<2>, grid, block, 0, c->stream, a, bx, pp, c->d_pairpart);
+            hipLaunchKernelGGL(pair_rd_es_kernel<2>, grid, block, 0, sb, a, bx, pp, c->d_pairpart);
         else
-            hipLaunchKernelGGL(pair_rd_es_kernel<4>, grid, block, 0, c->stream, a, bx, pp, c->d_pairpart);
-        hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, c->stream, c->d_pairpart, ntile * ntile,
+            hipLaunchKernelGGL(pair_rd_es_kernel<4>, grid, block, 0, sb, a, bx, pp, c->d_pairpart);
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, sb, c->d_pairpart, ntile * ntile,
                            kPairChannels, c->d_res + R_RD_PAIR);
     }
 
     // ---- reciprocal + self
     if (!P.rd_only) {
-        ScopedTimer t(c, T_RECIP);
+        ScopedTimer t(c, T_RECIP, sb);
         if (c->nk > 0) {
-            hipLaunchKernelGGL(ewald_recip_kernel, dim3(c->nk), dim3(256), 0, c->stream, a, c->d_kvec, c->d_perk);
-            hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, c->stream, c->d_perk, c->nk, 1,
+            hipLaunchKernelGGL(ewald_recip_kernel, dim3(c->nk), dim3(256), 0, sb, a, c->d_kvec, c->d_perk);
+            hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, sb, c->d_perk, c->nk, 1,
                                c->d_res + R_RECIP);
         } else {
-            HIPCHK(hipMemsetAsync(c->d_res + R_RECIP, 0, sizeof(double), c->stream));
+            HIPCHK(hipMemsetAsync(c->d_res + R_RECIP, 0, sizeof(double), sb));
         }
-        hipLaunchKernelGGL(ewald_self_kernel, dim3(1), dim3(256), 0, c->stream, a, c->ewald_alpha,
-                           c->d_res + R_SELF);
+        hipLaunchKernelGGL(ewald_self_kernel, dim3(1), dim3(256), 0, sb, a, c->ewald_alpha, c->d_res + R_SELF);
     } else {
-        HIPCHK(hipMemsetAsync(c->d_res + R_RECIP, 0, 2 * sizeof(double), c->stream));
+        HIPCHK(hipMemsetAsync(c->d_res + R_RECIP, 0, 2 * sizeof(double), sb));
     }
+    if (c->opt_overlap) hipEventRecord(c->ev_join, sb);
+
+    // ---- polarization (main stream)
+    const bool do_polar = !P.rd_only && P.polarization;
+    if (do_polar) {
+        if (run_polarization(c, a, bx, &polar_iterations, &iter_success)) return -1;
+    } else {
+        HIPCHK(hipMemsetAsync(c->d_res + R_UPOL, 0, 2 * sizeof(double), c->stream));
+    }
+    // the resident A only tracks moves while it is being maintained
+    if (!do_polar || P.polar_zodid) c->view[0].A_valid = false;
+    if (c->opt_overlap) hipStreamWaitEvent(c->stream, c->ev_join, 0);
     hipEventRecord(c->ev_last, c->stream);
     HIPCHK(hipMemcpyAsync(c->h_res, c->d_res, R_COUNT * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipGetLastError());
     c->timed = true;
+    c->dirty_atoms.clear();
+    c->all_dirty = false;
 
     const double *r = c->h_res;
     const double rd = r[R_RD_PAIR] + r[R_LRC];
@@ -604,24 +686,31 @@ extern "C" int mpmc_hip_energy(mpmc_hip_ctx *c, mpmc_hip_result *out) {
 extern "C" int mpmc_hip_download_dipoles(mpmc_hip_ctx *c, double *mu, double *ef_static, double *ef_induced,
                                          double *ef_induced_change) {
     if (!c || !c->have_atoms) return fail("MPMC_HIP: download_dipoles: no configuration");
+    if (!c->have_polar_result) return fail("MPMC_HIP: download_dipoles: no polarization energy evaluated yet");
     HIPCHK(hipSetDevice(c->device));
     const size_t b = 3 * (size_t)c->n * sizeof(double);
-    if (mu) {
-        if (!c->d_mu_final) return fail("MPMC_HIP: download_dipoles: no polarization energy evaluated yet");
-        HIPCHK(hipMemcpy(mu, c->d_mu_final, b, hipMemcpyDeviceToHost));
-    }
+    if (mu) HIPCHK(hipMemcpy(mu, c->d_mu, b, hipMemcpyDeviceToHost));
     if (ef_static) HIPCHK(hipMemcpy(ef_static, c->d_es, b, hipMemcpyDeviceToHost));
     if (ef_induced) HIPCHK(hipMemcpy(ef_induced, c->d_efind, b, hipMemcpyDeviceToHost));
     if (ef_induced_change) HIPCHK(hipMemcpy(ef_induced_change, c->d_efchg, b, hipMemcpyDeviceToHost));
     return 0;
 }
 
+// The solver keeps only the polarizable block of A on the device; the full 3N x 3N matrix of the
+// reference (system->A_matrix, read e.g. by vdw.c:244) is produced here on demand.
 extern "C" int mpmc_hip_download_amatrix(mpmc_hip_ctx *c, double *A) {
-    if (!c || !c->d_A || !A) return fail("MPMC_HIP: download_amatrix: no A matrix built");
+    if (!c || !c->have_atoms || !c->have_box || !A) return fail("MPMC_HIP: download_amatrix: no configuration");
     HIPCHK(hipSetDevice(c->device));
     const size_t n3 = 3 * (size_t)c->n, lda = 3 * (size_t)c->npad;
-    HIPCHK(hipMemcpy2D(A, n3 * sizeof(double), c->d_A, lda * sizeof(double), n3 * sizeof(double), n3,
-                       hipMemcpyDeviceToHost));
+    double *dA = nullptr;
+    HIPCHK(hipMalloc((void **)&dA, lda * lda * sizeof(double)));
+    hipLaunchKernelGGL(build_amatrix_kernel, dim3(c->npad / 128, c->npad / kARows), dim3(64), 0, c->stream,
+                       dev_atoms(c), dev_box(c), c->par.polar_damp, dA, (int)lda);
+    hipError_t e = hipMemcpy2DAsync(A, n3 * sizeof(double), dA, lda * sizeof(double), n3 * sizeof(double), n3,
+                                    hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(dA);
+    if (e != hipSuccess) return fail("MPMC_HIP: download_amatrix: %s", hipGetErrorString(e));
     return 0;
 }
 

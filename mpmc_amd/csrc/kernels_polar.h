@@ -90,15 +90,22 @@ __global__ __launch_bounds__(64) void static_field_kernel(DevAtoms a, DevBox bx,
 }
 
 // es[3i+p] = sum over chunks (fixed order) [+ accumulate into existing when add != 0]
-__global__ __launch_bounds__(256) void field_reduce_kernel(const double *__restrict__ part, int nchunk, int npad,
-                                                            double *__restrict__ es, int add) {
+__global__ __launch_bounds__(64) void field_reduce_kernel(const double *__restrict__ part, int nchunk, int npad,
+                                                           double *__restrict__ es, int add) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npad) return;
-    for (int p = 0; p < 3; ++p) {
-        double acc = add ? es[3 * i + p] : 0.0;
-        for (int c = 0; c < nchunk; ++c) acc += part[((size_t)c * 3 + p) * npad + i];
-        es[3 * i + p] = acc;
+    double a0 = add ? es[3 * i] : 0.0, a1 = add ? es[3 * i + 1] : 0.0, a2 = add ? es[3 * i + 2] : 0.0;
+    const size_t np = (size_t)npad;
+#pragma unroll 4
+    for (int c = 0; c < nchunk; ++c) {
+        const double *p = part + (size_t)c * 3 * np + i;
+        a0 += p[0];
+        a1 += p[np];
+        a2 += p[2 * np];
     }
+    es[3 * i] = a0;
+    es[3 * i + 1] = a1;
+    es[3 * i + 2] = a2;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -201,6 +208,65 @@ __global__ __launch_bounds__(64) void build_amatrix_kernel(DevAtoms a, DevBox bx
     }
 }
 
+// Incremental A update after an MC move: only the block-rows and block-columns of the moved
+// (polarizable) atoms change.  The matrix stays resident in HBM between energy() calls, so a
+// single-molecule displacement costs O(N m) tensor evaluations and ~2 N m 72-byte writes instead of
+// the reference's O(N^2) rebuild (thole_matrix.c:58-143 every step).  Every rewritten entry is the
+// same function of the same coordinates as in a full build, hence bit-identical to it.
+// grid = (nvpad/128 [column tiles], ndirty); block = 64.
+__global__ __launch_bounds__(64) void update_amatrix_kernel(DevAtoms a, DevBox bx, double damp,
+                                                             const int *__restrict__ dirty,
+                                                             double *__restrict__ A, int lda) {
+    const int lane = threadIdx.x;
+    const int j0 = blockIdx.x * 128 + 2 * lane;
+    const int i = dirty[blockIdx.y];
+    const double xi = a.x[i], yi = a.y[i], zi = a.z[i], ali = a.alpha[i];
+    const bool vi = a.flags[i] & kValid;
+    const double2 xj = *reinterpret_cast<const double2 *>(a.x + j0);
+    const double2 yj = *reinterpret_cast<const double2 *>(a.y + j0);
+    const double2 zj = *reinterpret_cast<const double2 *>(a.z + j0);
+    const int2 flj = *reinterpret_cast<const int2 *>(a.flags + j0);
+    double t0[6], t1[6];
+#pragma unroll
+    for (int u = 0; u < 6; ++u) t0[u] = t1[u] = 0.0;
+    const double dg = (ali != 0.0) ? 1.0 / ali : kMAXVALUE;
+    if (vi && (flj.x & kValid)) {
+        if (j0 == i)
+            t0[0] = t0[3] = t0[5] = dg;
+        else
+            thole_tensor(bx, damp, xi - xj.x, yi - yj.x, zi - zj.x, t0[0], t0[1], t0[2], t0[3], t0[4], t0[5]);
+    }
+    if (vi && (flj.y & kValid)) {
+        if (j0 + 1 == i)
+            t1[0] = t1[3] = t1[5] = dg;
+        else
+            thole_tensor(bx, damp, xi - xj.y, yi - yj.y, zi - zj.y, t1[0], t1[1], t1[2], t1[3], t1[4], t1[5]);
+    }
+    // block-row i (coalesced 16-byte stores, as in the full build)
+    double *r0 = A + (size_t)(3 * i) * lda + 3 * (size_t)j0;
+    double2 *v0 = reinterpret_cast<double2 *>(r0);
+    double2 *v1 = reinterpret_cast<double2 *>(r0 + lda);
+    double2 *v2 = reinterpret_cast<double2 *>(r0 + 2 * (size_t)lda);
+    v0[0] = make_double2(t0[0], t0[1]);
+    v0[1] = make_double2(t0[2], t1[0]);
+    v0[2] = make_double2(t1[1], t1[2]);
+    v1[0] = make_double2(t0[1], t0[3]);
+    v1[1] = make_double2(t0[4], t1[1]);
+    v1[2] = make_double2(t1[3], t1[4]);
+    v2[0] = make_double2(t0[2], t0[4]);
+    v2[1] = make_double2(t0[5], t1[2]);
+    v2[2] = make_double2(t1[4], t1[5]);
+    // block-column i: the (j,i) block equals the (i,j) block (T is symmetric as a 3x3 and even in d)
+    double *c0 = A + (size_t)(3 * j0) * lda + 3 * (size_t)i;
+    c0[0] = t0[0]; c0[1] = t0[1]; c0[2] = t0[2];
+    c0[lda] = t0[1]; c0[lda + 1] = t0[3]; c0[lda + 2] = t0[4];
+    c0[2 * (size_t)lda] = t0[2]; c0[2 * (size_t)lda + 1] = t0[4]; c0[2 * (size_t)lda + 2] = t0[5];
+    double *c1 = c0 + 3 * (size_t)lda;
+    c1[0] = t1[0]; c1[1] = t1[1]; c1[2] = t1[2];
+    c1[lda] = t1[1]; c1[lda + 1] = t1[3]; c1[lda + 2] = t1[4];
+    c1[2 * (size_t)lda] = t1[2]; c1[2 * (size_t)lda + 1] = t1[4]; c1[2 * (size_t)lda + 2] = t1[5];
+}
+
 // ---------------------------------------------------------------------------------------------
 // Dipole sweep = one pass over A (reference src/polarization/thole_iterative.c:27-59 with
 // Jacobi ordering, plus the bookkeeping of :186-252 fused into the epilogue):
@@ -211,9 +277,17 @@ __global__ __launch_bounds__(64) void build_amatrix_kernel(DevAtoms a, DevBox bx
 // out rather than subtracted afterwards (it holds 1/alpha; subtracting would cost a digit).
 // MODE_PALMO reuses the same pass: dE_i = -E_ind,i - sum_{j != i} T_ij mu_j
 // (thole_iterative.c:119-141), for every atom including non-polarizable ones.
-// grid = npad/4; block = 256 (4 waves = 4 atoms).
+// grid = npad; block = 64 (one wave = one atom): single-wave workgroups let the dispatcher balance
+// the ~13 waves/CU evenly (4-wave workgroups left CUs with 3 or 4 of them: a 25 % tail).
 // ---------------------------------------------------------------------------------------------
 enum SweepMode { kSweepJacobi = 0, kSweepPalmo = 1 };
+
+typedef double native_double2 __attribute__((ext_vector_type(2)));
+// 16-byte non-temporal load (global_load_dwordx4 ... nt)
+__device__ __forceinline__ double2 stream_load2(const double *p) {
+    const native_double2 v = __builtin_nontemporal_load(reinterpret_cast<const native_double2 *>(p));
+    return make_double2(v.x, v.y);
+}
 
 struct SweepParams {
     double w_new;    // weight of new_mu in mu_out (1 for plain Jacobi)
@@ -223,7 +297,7 @@ struct SweepParams {
 };
 
 template <int MODE>
-__global__ __launch_bounds__(256) void sweep_kernel(const double *__restrict__ A, int lda, int npad,
+__global__ __launch_bounds__(64) void sweep_kernel(const double *__restrict__ A, int lda, int npad,
                                                      const double *__restrict__ alpha,
                                                      const int *__restrict__ flags,
                                                      const double *__restrict__ mu_in,
@@ -232,8 +306,8 @@ __global__ __launch_bounds__(256) void sweep_kernel(const double *__restrict__ A
                                                      double *__restrict__ out,          // mu_out | ef_induced_change
                                                      double *__restrict__ rrms,
                                                      unsigned long long *__restrict__ errmax, SweepParams sp) {
-    const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x;
+    const int i = blockIdx.x;
     const double al = alpha[i];
     const int fl = flags[i];
     if (MODE == kSweepJacobi) {
@@ -262,9 +336,10 @@ __global__ __launch_bounds__(256) void sweep_kernel(const double *__restrict__ A
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
             const int c = c0 + 128 * u;
-            r0[u] = *reinterpret_cast<const double2 *>(a0 + c);
-            r1[u] = *reinterpret_cast<const double2 *>(a1 + c);
-            r2[u] = *reinterpret_cast<const double2 *>(a2 + c);
+            // A is streamed exactly once per sweep: non-temporal loads keep it from evicting mu / E
+            r0[u] = stream_load2(a0 + c);
+            r1[u] = stream_load2(a1 + c);
+            r2[u] = stream_load2(a2 + c);
             m[u] = *reinterpret_cast<const double2 *>(mu_in + c);
         }
 #pragma unroll
@@ -350,7 +425,7 @@ __global__ __launch_bounds__(256) void fallback_dipoles_kernel(int npad, const d
 
 // U_pol = -1/2 sum_i mu_i . E_static,i (+ mu_i . dE_ind,i with polar_palmo)   (polar.c:107-116)
 // and observables->dipole_rrms = mean_i rrms_i (polar.c:13-28).  One block, fixed order.
-__global__ __launch_bounds__(256) void polar_energy_kernel(int n, const double *__restrict__ mu,
+__global__ __launch_bounds__(256) void polar_energy_kernel(int n, int n_total, const double *__restrict__ mu,
                                                             const double *__restrict__ es,
                                                             const double *__restrict__ ef_change, int palmo,
                                                             const double *__restrict__ rrms,
@@ -375,7 +450,7 @@ __global__ __launch_bounds__(256) void polar_energy_kernel(int n, const double *
     __syncthreads();
     if (threadIdx.x == 0) {
         out[0] = -0.5 * ((s[0] + s[1]) + (s[2] + s[3]));
-        out[1] = ((t[0] + t[1]) + (t[2] + t[3])) / (double)n;
+        out[1] = ((t[0] + t[1]) + (t[2] + t[3])) / (double)n_total;  // mean over ALL atoms (polar.c:21-27)
     }
 }
 

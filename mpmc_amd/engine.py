@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libmpmc_hip.so")
 # every symbol include/mpmc_hip.h declares
 EXPORTS = [
     "mpmc_hip_last_error", "mpmc_hip_abi_version", "mpmc_hip_device_count", "mpmc_hip_create",
-    "mpmc_hip_destroy", "mpmc_hip_default_params", "mpmc_hip_set_params", "mpmc_hip_set_box",
+    "mpmc_hip_destroy", "mpmc_hip_set_option", "mpmc_hip_default_params", "mpmc_hip_set_params", "mpmc_hip_set_box",
     "mpmc_hip_upload", "mpmc_hip_update_atoms", "mpmc_hip_energy", "mpmc_hip_download_dipoles",
     "mpmc_hip_download_amatrix", "mpmc_hip_download_ranking", "mpmc_hip_get_timings",
     "mpmc_hip_comm_unique_id", "mpmc_hip_comm_create", "mpmc_hip_allreduce_observables",
@@ -111,6 +111,7 @@ def load():
     lib.mpmc_hip_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int]
     lib.mpmc_hip_destroy.argtypes = [vp]
     lib.mpmc_hip_destroy.restype = None
+    lib.mpmc_hip_set_option.argtypes = [vp, C.c_char_p, C.c_int]
     lib.mpmc_hip_default_params.argtypes = [C.POINTER(Params)]
     lib.mpmc_hip_default_params.restype = None
     lib.mpmc_hip_set_params.argtypes = [vp, C.POINTER(Params)]
@@ -175,6 +176,9 @@ class Engine:
     def set_params(self, **kw):
         p = kw.pop("_struct", None) or make_params(**kw)
         _chk(self.lib.mpmc_hip_set_params(self.ctx, C.byref(p)))
+
+    def set_option(self, name, value):
+        _chk(self.lib.mpmc_hip_set_option(self.ctx, name.encode(), int(value)))
 
     def set_box(self, basis, pbc_cutoff=0.0):
         b = np.ascontiguousarray(basis, dtype=np.float64).reshape(9)
