@@ -2,8 +2,9 @@
 """bench.py -- MC steps/s of the polarizable 4096-atom box on N x MI355X (one walker per GPU).
 
 One "step" = one single-molecule displacement (translate + rotate, reference
-src/mc/mc_moves.c:378-488) + one FULL energy() on the device through the C ABI + Metropolis
-(reference src/mc/mc.c:294-353), exactly what the reference does per step.  Workload: the
+src/mc/mc_moves.c:378-488) + one energy() on the device through the C ABI + Metropolis
+(reference src/mc/mc.c:294-353), exactly what the reference does per step; the loop itself is the
+C host layer of host/ (system_t, energy(), checkpoint/make_move/restore), called via ctypes.  Workload: the
 4096-atom PCN-61 cell + 416 BSSP H2 of tests/golden/pcn61_bssp_4096.npz with the flags of the
 reference's sample_configs_gpu/3_PCN61/iter.inp run as NVT (Jacobi x4, cutoff 8 A, FH 4th order)
 -- BASELINE.json configs[3]; `--workload` selects the synthetic boxes instead.
@@ -46,60 +47,6 @@ def load_workload(name):
     if kind == "slj":
         return synth.s_lj(n), dict(synth.FLAGS_LJ), "S-LJ(%d): LJ only" % n
     raise SystemExit("unknown workload " + name)
-
-
-class Walker:
-    """Minimal NVT Markov chain around the engine (host control; the energy is the hot path)."""
-
-    def __init__(self, eng, system, flags, seed, move_factor=0.01, rot_factor=0.01):
-        self.eng = eng
-        self.pos = np.array(system["pos"], dtype=np.float64)
-        self.mass = np.asarray(system["mass"], dtype=np.float64)
-        mol = np.asarray(system["molecule"])
-        frozen = np.asarray(system["frozen"])
-        starts = np.flatnonzero(np.r_[True, mol[1:] != mol[:-1]])
-        ends = np.r_[starts[1:], len(mol)]
-        self.movable = [(int(a), int(b)) for a, b in zip(starts, ends) if not frozen[a]]
-        self.rng = np.random.default_rng(seed)
-        self.T = flags["temperature"]
-        self.move_factor = move_factor
-        self.rot_factor = rot_factor
-        self.cutoff = None
-        self.energy = None
-        self.accepted = 0
-
-    def initial(self):
-        r = self.eng.energy()
-        self.energy = r["energy"]
-        self.cutoff = r["cutoff"]
-        return r
-
-    def step(self):
-        a, b = self.movable[self.rng.integers(len(self.movable))]
-        old = self.pos[a:b].copy()
-        m = self.mass[a:b]
-        com = (m[:, None] * old).sum(0) / m.sum() if m.sum() > 0 else old.mean(0)
-        # translate: +-scale*U*cutoff per axis (mc_moves.c:378-398)
-        t = self.move_factor * self.rng.random(3) * self.cutoff * np.where(self.rng.random(3) < 0.5, -1.0, 1.0)
-        # rotate about a random axis by U*360*scale degrees (mc_moves.c:402-465)
-        ax = self.rng.random(3) - 0.5
-        ax /= np.linalg.norm(ax)
-        ang = np.deg2rad(self.rng.random() * 360.0 * self.rot_factor)
-        K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
-        R = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * (K @ K)
-        new = (old - com) @ R.T + com + t
-        self.eng.update_atoms(a, new)
-        r = self.eng.energy()
-        e_new = r["energy"]
-        ok = np.isfinite(e_new) and r["iter_success"] == 0 and \
-            self.rng.random() < np.exp(min(0.0, -(e_new - self.energy) / self.T))
-        if ok:
-            self.pos[a:b] = new
-            self.energy = e_new
-            self.accepted += 1
-        else:
-            self.eng.update_atoms(a, old)  # restore(); the next energy() recomputes everything anyway
-        return r
 
 
 def cpu_baseline(system, flags, budget_s=20.0):
@@ -148,15 +95,14 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
 
-    from mpmc_amd import engine
+    from mpmc_amd import host
+    from mpmc_amd.walkers import WalkerAverages
 
     system, flags, label = load_workload(args.workload)
     n = len(system["charge"])
-    eng = engine.Engine(n, device=local_rank)
-    eng.load_system(system, flags)
-    walker = Walker(eng, system, flags, seed=args.seed + rank)
-    walker.initial()
-    obs = torch.zeros(8, dtype=torch.float64, device=dev)
+    # host control stays in C: system_t + energy() + the NVT chain of host/ drive the engine through the C ABI
+    chain = host.HostSystem(system, flags, device=local_rank, seed=args.seed + rank)
+    avg = WalkerAverages(dist=dist, device=dev)
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -164,32 +110,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def run(nsteps, collect):
-        acc = dict(sweep_ms=0.0, sweep_count=0, amatrix_ms=0.0, pair_ms=0.0, recip_ms=0.0, field_ms=0.0,
-                   palmo_ms=0.0, other_ms=0.0, total_ms=0.0)
-        esum = np.zeros(8)
-        for k in range(1, nsteps + 1):
-            r = walker.step()
-            esum += [1.0, walker.energy, walker.energy ** 2, r["rd_energy"], r["coulombic_energy"],
-                     r["polarization_energy"], r["polar_iterations"], 0.0]
-            if collect:
-                t = eng.timings()
-                for key in acc:
-                    acc[key] += t[key]
-            if k % args.corrtime == 0:
-                # walker averaging every corrtime (reference mc.c:417-432: MPI_Gather of observables)
-                obs.copy_(torch.from_numpy(esum))
-                if dist is not None:
-                    dist.all_reduce(obs)
-                esum[:] = 0.0
-        return acc
+    def run(nsteps):
+        done = 0
+        while done < nsteps:
+            k = min(args.corrtime, nsteps - done)
+            acc = chain.mc_steps(k)
+            done += k
+            o = chain.observables()
+            avg.add(o["energy"], o["rd_energy"], o["coulombic_energy"], o["polarization_energy"],
+                    o["polar_iterations"], acc / float(k))
+            # walker averaging every corrtime (reference mc.c:417-432: MPI_Gather of observables)
+            avg.reduce()
 
-    run(args.warmup, False)
+    run(args.warmup)
+    chain.enable_timing(True)
     sync()
     t0 = time.perf_counter()
-    acc = run(args.steps, True)
+    run(args.steps)
     sync()
     elapsed = time.perf_counter() - t0
+    acc = chain.timings()
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -236,12 +176,12 @@ def main():
             "device_ms_per_step": {k: acc[k] / args.steps for k in
                                    ("pair_ms", "recip_ms", "field_ms", "amatrix_ms", "sweep_ms", "palmo_ms",
                                     "other_ms", "total_ms")},
-            "acceptance": walker.accepted / float(args.steps + args.warmup),
+            "walker_averages": avg.summary(),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(system, flags)
         print(json.dumps(out))
-    eng.close()
+    chain.close()
     if dist is not None:
         dist.destroy_process_group()
 

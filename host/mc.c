@@ -1,0 +1,271 @@
+/*
+ * mc.c -- canonical (NVT) Markov chain, host side; mirrors the control flow of the reference's
+ * mc() (src/mc/mc.c:196-525), checkpoint()/restore() (src/mc/checkpoint.c:4-186,
+ * src/mc/mc_moves.c:744-807), make_move()/displace() (src/mc/mc_moves.c:378-488, :567-741) and
+ * get_rand() (src/mersenne/mersenne.cpp:9-22) for the displacement move.  Random numbers are
+ * consumed in the reference's order: pick molecule, 6 for translate, 4 for rotate, 1 for Metropolis.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "mpmc_host.h"
+
+/* ---- std::mt19937 + std::uniform_real_distribution<double>(0,1) as libstdc++ evaluates it:
+ * generate_canonical<double,53> draws two 32-bit words, sum = w0 + w1 * 2^32, result sum / 2^64. */
+static unsigned int mt[624];
+static int mti = 625;
+
+void seed_rng(unsigned int seed) {
+    mt[0] = seed;
+    for (mti = 1; mti < 624; mti++) mt[mti] = 1812433253u * (mt[mti - 1] ^ (mt[mti - 1] >> 30)) + (unsigned int)mti;
+}
+
+static unsigned int mt_next(void) {
+    if (mti >= 624) {
+        if (mti == 625) seed_rng(5489u);
+        for (int k = 0; k < 624; k++) {
+            unsigned int y = (mt[k] & 0x80000000u) | (mt[(k + 1) % 624] & 0x7fffffffu);
+            mt[k] = mt[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        mti = 0;
+    }
+    unsigned int y = mt[mti++];
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
+double get_rand(system_t *system) {
+    if (!system->rng_initialized) {
+        system->rng_initialized = 1;
+        if (system->preset_seeds_on)
+            seed_rng(system->preset_seeds);
+        else {
+            unsigned int s = 5489u;
+            FILE *f = fopen("/dev/urandom", "rb");
+            if (f) {
+                if (fread(&s, sizeof(s), 1, f) != 1) s = 5489u;
+                fclose(f);
+            }
+            seed_rng(s);
+        }
+    }
+    double sum = 0.0, tmp = 1.0;
+    for (int k = 0; k < 2; k++) {
+        sum += (double)mt_next() * tmp;
+        tmp *= 4294967296.0;
+    }
+    double ret = sum / tmp;
+    if (ret >= 1.0) ret = nextafter(1.0, 0.0);
+    return ret;
+}
+
+/* ---- moves ---------------------------------------------------------------------------------- */
+void translate(system_t *system, molecule_t *molecule, pbc_t *pbc, double scale) {
+    double trans_x = scale * get_rand(system) * pbc->cutoff;
+    double trans_y = scale * get_rand(system) * pbc->cutoff;
+    double trans_z = scale * get_rand(system) * pbc->cutoff;
+    if (get_rand(system) < 0.5) trans_x *= -1.0;
+    if (get_rand(system) < 0.5) trans_y *= -1.0;
+    if (get_rand(system) < 0.5) trans_z *= -1.0;
+    molecule->com[0] += trans_x;
+    molecule->com[1] += trans_y;
+    molecule->com[2] += trans_z;
+    for (atom_t *a = molecule->atoms; a; a = a->next) {
+        a->pos[0] += trans_x;
+        a->pos[1] += trans_y;
+        a->pos[2] += trans_z;
+    }
+}
+
+typedef struct { double x, y, z, w; } quat_t;
+static quat_t qmul(quat_t a, quat_t b) { /* reference src/main/quaternion.c:65-75 */
+    quat_t r;
+    r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+    r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+    r.y = a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x;
+    r.z = a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w;
+    return r;
+}
+
+void rotate(system_t *system, molecule_t *molecule, pbc_t *pbc, double scale) {
+    (void)pbc;
+    double x = get_rand(system) - 0.5;
+    double y = get_rand(system) - 0.5;
+    double z = get_rand(system) - 0.5;
+    double angle = get_rand(system) * 360 * scale;
+    quat_t q = {0., 0., 0., 1.}, qc;
+    angle /= 57.2957795; /* quaternion_construct_axis_angle_degree, quaternion.c:44-59 */
+    double magnitude = sqrt(x * x + y * y + z * z);
+    if (magnitude != 0.0) {
+        x /= magnitude;
+        y /= magnitude;
+        z /= magnitude;
+        double sinAngle = sin(angle / 2);
+        q.x = x * sinAngle;
+        q.y = y * sinAngle;
+        q.z = z * sinAngle;
+        q.w = cos(angle / 2);
+    }
+    qc.x = -q.x; qc.y = -q.y; qc.z = -q.z; qc.w = q.w;
+    const double com[3] = {molecule->com[0], molecule->com[1], molecule->com[2]};
+    for (atom_t *a = molecule->atoms; a; a = a->next) {
+        quat_t p = {a->pos[0] - com[0], a->pos[1] - com[1], a->pos[2] - com[2], 0.};
+        quat_t ans = qmul(q, qmul(p, qc));
+        a->pos[0] = ans.x + com[0];
+        a->pos[1] = ans.y + com[1];
+        a->pos[2] = ans.z + com[2];
+    }
+}
+
+/* choose the next molecule and back it up (reference checkpoint(), NVT/displace branch) */
+void checkpoint(system_t *system) {
+    checkpoint_t *cp = system->checkpoint;
+    memcpy(cp->observables, system->observables, sizeof(observables_t));
+    cp->movetype = MOVETYPE_DISPLACE;
+    /* altered = floor(rand * N) over the non-frozen molecules in list order (checkpoint.c:121-123) */
+    int altered = (int)floor(get_rand(system) * system->observables->N);
+    int k = 0, first = 0;
+    molecule_t *pick = NULL;
+    for (molecule_t *m = system->molecules; m; m = m->next) {
+        int cnt = 0;
+        for (atom_t *a = m->atoms; a; a = a->next) cnt++;
+        if (!m->frozen) {
+            if (k == altered) {
+                pick = m;
+                cp->altered_first = first;
+                cp->altered_count = cnt;
+                break;
+            }
+            k++;
+        }
+        first += cnt;
+    }
+    cp->molecule_altered = pick;
+    if (!pick) return;
+    cp->backup_pos = realloc(cp->backup_pos, 3 * (size_t)cp->altered_count * sizeof(double));
+    int i = 0;
+    for (atom_t *a = pick->atoms; a; a = a->next, i++)
+        for (int p = 0; p < 3; p++) cp->backup_pos[3 * i + p] = a->pos[p];
+    for (int p = 0; p < 3; p++) cp->backup_com[p] = pick->com[p];
+}
+
+void make_move(system_t *system) {
+    molecule_t *m = system->checkpoint->molecule_altered;
+    if (!m) return;
+    translate(system, m, system->pbc, system->move_factor);
+    rotate(system, m, system->pbc, system->rot_factor);
+}
+
+/* undo make_move() and pick the next move (reference restore(), mc_moves.c:744-807) */
+void restore(system_t *system) {
+    checkpoint_t *cp = system->checkpoint;
+    memcpy(system->observables, cp->observables, sizeof(observables_t));
+    if (cp->molecule_altered) {
+        int i = 0;
+        for (atom_t *a = cp->molecule_altered->atoms; a; a = a->next, i++)
+            for (int p = 0; p < 3; p++) a->pos[p] = cp->backup_pos[3 * i + p];
+        for (int p = 0; p < 3; p++) cp->molecule_altered->com[p] = cp->backup_com[p];
+    }
+    checkpoint(system);
+}
+
+/* reference boltzmann_factor(), NVT branch (mc.c:106-114) */
+void boltzmann_factor(system_t *system, double initial_energy, double final_energy) {
+    const double delta_energy = final_energy - initial_energy;
+    system->nodestats->boltzmann_factor = exp(-delta_energy / system->temperature);
+}
+
+/* reference write_observables(), src/io/output.c:988-1006 */
+static void write_observables(FILE *fp, system_t *system, observables_t *o, double core_temp) {
+    fprintf(fp, "%d %f %f %f %f %f %f %f %f %f %f %f\n", system->step, o->energy, o->coulombic_energy, o->rd_energy,
+            o->polarization_energy, o->vdw_energy, o->kinetic_energy, o->temperature, o->N, o->spin_ratio, o->volume,
+            core_temp);
+    fflush(fp);
+}
+
+static void update_averages(system_t *system) {
+    avg_observables_t *a = system->avg_observables;
+    observables_t *o = system->observables;
+    const double m = a->counter / (a->counter + 1.0), f = 1.0 / (a->counter + 1.0); /* running mean, average.c:213-229 */
+    a->energy = m * a->energy + f * o->energy;
+    a->energy_sq = m * a->energy_sq + f * o->energy * o->energy;
+    a->coulombic_energy = m * a->coulombic_energy + f * o->coulombic_energy;
+    a->rd_energy = m * a->rd_energy + f * o->rd_energy;
+    a->polarization_energy = m * a->polarization_energy + f * o->polarization_energy;
+    a->polarization_iterations = m * a->polarization_iterations + f * system->nodestats->polarization_iterations;
+    a->counter += 1.0;
+}
+
+/* implements the Markov chain */
+int mc(system_t *system) {
+    double initial_energy, final_energy;
+    char linebuf[MAXLINE];
+    system->observables->volume = system->pbc->volume;
+    system->observables->temperature = 0;
+
+    /* get the initial energy of the system */
+    system->step = 0;
+    initial_energy = energy(system);
+    /* be a bit forgiving of the initial state */
+    if (!isfinite(initial_energy)) initial_energy = system->observables->energy = MAXVALUE;
+
+    if (system->energy_output[0] && !system->fp_energy) {
+        system->fp_energy = fopen(system->energy_output, "w");
+        if (!system->fp_energy) {
+            error("MC: could not open files\n");
+            return -1;
+        }
+        fprintf(system->fp_energy,
+                "#step #energy #coulombic #rd #polar #vdw #kinetic #kin_temp #N #spin_ratio #volume #core_temp\n");
+    }
+    update_averages(system);
+    if (system->fp_energy) write_observables(system->fp_energy, system, system->observables, system->temperature);
+
+    /* save the initial state */
+    checkpoint(system);
+
+    /* main MC loop */
+    for (system->step = 1; system->step <= system->numsteps; (system->step)++) {
+        /* restore the last accepted energy */
+        initial_energy = system->observables->energy;
+        /* perturb the system */
+        make_move(system);
+        /* calculate the energy change */
+        final_energy = energy(system);
+        /* treat a bad contact as a reject */
+        if (!isfinite(final_energy)) {
+            system->observables->energy = MAXVALUE;
+            system->nodestats->boltzmann_factor = 0;
+        } else
+            boltzmann_factor(system, initial_energy, final_energy);
+
+        /* Metropolis function */
+        if ((get_rand(system) < system->nodestats->boltzmann_factor) && (system->iter_success == 0)) {
+            checkpoint(system);
+            ++system->nodestats->accept;
+            ++system->nodestats->accept_displace;
+        } else {
+            system->iter_success = 0; /* reset the polar iterative failure flag */
+            restore(system);
+            ++system->nodestats->reject;
+            ++system->nodestats->reject_displace;
+        }
+        system->nodestats->acceptance_rate =
+            (double)system->nodestats->accept / (double)(system->nodestats->accept + system->nodestats->reject);
+
+        /* do this every correlation time */
+        if (!(system->step % system->corrtime)) {
+            update_averages(system);
+            if (system->fp_energy)
+                write_observables(system->fp_energy, system, system->observables, system->temperature);
+        }
+    }
+    snprintf(linebuf, MAXLINE, "MC: %d steps, acceptance rate %.4f, <E> = %.6f K\n", system->numsteps,
+             system->nodestats->acceptance_rate, system->avg_observables->energy);
+    output(linebuf);
+    return 0;
+}

@@ -1,0 +1,73 @@
+"""GPU tests of the C host layer: energy(system_t*) and the NVT chain driven from C, against the
+oracle; the stand-alone driver on a reference-style input directory."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from mpmc_amd import engine, host, synth
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_host_energy_matches_oracle_and_engine():
+    s = synth.s_pol(640)
+    p = dict(synth.FLAGS_POL_JACOBI)
+    h = host.HostSystem(s, p, seed=3)
+    e = h.energy()
+    want = oracle.energy(s, p)
+    assert abs(e - want["energy"]) < 1e-9 * abs(want["energy"])
+    o = h.observables()
+    assert abs(o["polarization_energy"] - want["polarization_energy"]) < 1e-9 * abs(want["polarization_energy"])
+    assert o["N"] == 128 and o["polar_iterations"] == 10
+    d = h.dipoles()
+    wv = oracle.energy(s, p, want_vectors=True)
+    assert np.abs(d["mu"] - wv["mu"]).max() < 1e-10 * np.abs(wv["mu"]).max()
+    h.close()
+
+
+def test_host_chain_tracks_the_oracle():
+    """Run the C Markov chain; after a run of accepted and rejected moves the energy the chain
+    carries must equal the oracle's energy of the chain's current configuration."""
+    s = synth.s_pol(320)
+    p = dict(temperature=77.0, polarization=1, polar_damp=2.1304, polar_max_iter=4, polar_gs=1, polar_palmo=1)
+    h = host.HostSystem(s, p, seed=11, move_factor=0.05, rot_factor=0.05)
+    acc = h.mc_steps(60)
+    o = h.observables()
+    assert o["accept"] == acc and o["accept"] + o["reject"] == 60 and 0 < acc
+    s2 = dict(s)
+    s2["pos"] = h.positions()
+    want = oracle.energy(s2, p)
+    assert abs(o["energy"] - want["energy"]) < 1e-9 * abs(want["energy"])
+    h.close()
+
+
+def test_same_seed_same_chain():
+    s = synth.s_pol(160)
+    p = dict(synth.FLAGS_POL_JACOBI)
+    out = []
+    for _ in range(2):
+        h = host.HostSystem(s, p, seed=99, move_factor=0.05, rot_factor=0.05)
+        h.mc_steps(30)
+        out.append((h.observables()["energy"], h.positions()))
+        h.close()
+    assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1])
+
+
+def test_driver_executable_on_reference_style_input():
+    """mpmc_hip <input> on the 10-atom box: the step-0 line of its energy_output must carry the
+    reference's golden numbers (sample_configs_gpu/cuda_pol.small/noncuda_control/small.energy.dat:2)."""
+    out = "/tmp/mpmc_hip_small.energy.dat"
+    if os.path.exists(out):
+        os.remove(out)
+    r = subprocess.run([host.EXE_PATH, os.path.join(ROOT, "tests", "data", "bssp_small", "input")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = open(out).read().splitlines()
+    assert lines[0].startswith("#step #energy #coulombic #rd #polar")
+    t = lines[1].split()
+    assert t[:5] == ["0", "-22.738394", "1.993547", "-24.673480", "-0.058461"]
+    assert [l.split()[0] for l in lines[1:]] == ["0", "10", "20", "30", "40"]
