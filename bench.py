@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--corrtime", type=int, default=10)
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--full-sweep", action="store_true", help="A/B: stream the full matrix instead of its upper triangle")
+    ap.add_argument("--full-rebuild", action="store_true", help="A/B: rebuild A from scratch every step")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -103,6 +105,10 @@ def main():
     # host control stays in C: system_t + energy() + the NVT chain of host/ drive the engine through the C ABI
     chain = host.HostSystem(system, flags, device=local_rank, seed=args.seed + rank)
     avg = WalkerAverages(dist=dist, device=dev)
+    if args.full_sweep or args.full_rebuild:
+        chain.energy()  # creates the device context
+        chain.set_option("symmetric_sweep", 0 if args.full_sweep else 1)
+        chain.set_option("incremental_amatrix", 0 if args.full_rebuild else 1)
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -138,11 +144,14 @@ def main():
     if rank == 0:
         value = world * args.steps / elapsed
         sweep_avg_ms = acc["sweep_ms"] / max(1, acc["sweep_count"])
-        # algorithmic bytes of one sweep launch: the polarizable block of A, (3 n_pol)^2 fp64, read
-        # once (sites with alpha = 0 carry no dipole: neither their rows nor their columns are
-        # needed, cf. contract_dipoles) + mu, E_static in and mu, E_ind out
+        # algorithmic bytes of one sweep launch (symv_kernel): the UPPER TRIANGLE of the polarizable
+        # block of A (symmetric; sites with alpha = 0 carry no dipole, so neither their rows nor their
+        # columns exist), fp64, read once, + mu in and the row/column partial sums out
         n_pol = int(np.count_nonzero(np.asarray(system["alpha"]) != 0.0))
-        sweep_bytes = (3.0 * n_pol) ** 2 * 8 + 5 * 3 * n_pol * 8
+        m3 = 3.0 * n_pol
+        sweep_bytes = m3 * (m3 + 1) / 2 * 8 + 3 * m3 * 8
+        if args.full_sweep:
+            sweep_bytes = m3 * m3 * 8 + 5 * m3 * 8
         achieved = sweep_bytes / (sweep_avg_ms * 1e-3) / 1e9 if sweep_avg_ms > 0 else 0.0
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "sweep_pmc_latest.json")
@@ -168,7 +177,8 @@ def main():
                     "random MC moves",
             "config": {"workload": label, "n_atoms": n, "n_polarizable": n_pol, "walkers": world, "corrtime": args.corrtime,
                        "parallelism": "%d independent walkers, 1 per GPU" % world},
-            "roofline": {"kernel": "sweep_kernel<Jacobi> (Thole field / dipole sweep)", "bound": "hbm",
+            "roofline": {"kernel": ("sweep_kernel<Jacobi>" if args.full_sweep else "symv_kernel") +
+                                   " (Thole field / dipole sweep)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": sweep_avg_ms, "launches": acc["sweep_count"],

@@ -111,3 +111,8 @@ void host_init_chain_no_energy(system_t *system) {
         if (!m->frozen) system->observables->N += 1.0;
     checkpoint(system);
 }
+
+int host_set_option(system_t *system, const char *name, int value) {
+    if (!system->hip_ctx) return -1;
+    return mpmc_hip_set_option(system->hip_ctx, name, value);
+}

@@ -111,7 +111,9 @@ void mpmc_hip_destroy(mpmc_hip_ctx *ctx);
  *   "incremental_amatrix" (default 1): after mpmc_hip_update_atoms() rewrite only the moved atoms'
  *                          block-rows/-columns of the resident A matrix instead of rebuilding it;
  *   "overlap_streams"     (default 1): run the LJ/Ewald kernels on a second HIP stream beside the
- *                          polarization chain. */
+ *                          polarization chain;
+ *   "symmetric_sweep"     (default 1): Jacobi/Palmo sweeps read only the upper triangle of A and use
+ *                          every element for both products (half the HBM bytes); 0 = full-matrix sweep. */
 int mpmc_hip_set_option(mpmc_hip_ctx *ctx, const char *name, int value);
 
 void mpmc_hip_default_params(mpmc_hip_params *p);

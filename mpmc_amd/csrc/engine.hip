@@ -27,6 +27,7 @@
 #include "kernels_gs.h"
 #include "kernels_pair.h"
 #include "kernels_polar.h"
+#include "kernels_symv.h"
 
 using namespace mpmc;
 
@@ -102,6 +103,8 @@ struct SweepView {
     std::vector<int> slot_of_atom;  // atom index -> view slot, -1 if not in the view
     double *es = nullptr, *mu0 = nullptr, *mu1 = nullptr, *munew = nullptr, *y = nullptr, *efind = nullptr,
            *efchg = nullptr, *rrms = nullptr;
+    double *Srow = nullptr, *Zcol = nullptr;  // partial sums of the symmetric sweep
+    size_t symcap = 0;
     std::vector<int> h_idx;
 };
 
@@ -122,7 +125,7 @@ struct mpmc_hip_ctx {
     bool have_polar_result = false;
     std::vector<int> dirty_atoms;   // atoms moved by update_atoms() since the last energy()
     bool all_dirty = true;
-    int opt_incremental = 1, opt_overlap = 1;
+    int opt_incremental = 1, opt_overlap = 1, opt_symmetric = 1;
     int *h_dirty = nullptr;         // pinned staging for dirty slots
     hipStream_t stream2 = nullptr;  // pair / reciprocal kernels overlap the polarization chain
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -214,6 +217,8 @@ extern "C" int mpmc_hip_set_option(mpmc_hip_ctx *c, const char *name, int value)
         c->all_dirty = true;
     } else if (!strcmp(name, "overlap_streams"))
         c->opt_overlap = value;
+    else if (!strcmp(name, "symmetric_sweep"))
+        c->opt_symmetric = value;
     else
         return fail("MPMC_HIP: set_option: unknown option '%s'", name);
     return 0;
@@ -319,7 +324,7 @@ extern "C" void mpmc_hip_destroy(mpmc_hip_ctx *c) {
     for (void *p : dptrs)
         if (p) hipFree(p);
     for (SweepView &v : c->view) {
-        void *vp[] = {v.d_idx, v.d_dirty, v.px, v.py, v.pz, v.palpha, v.pflags, v.A,    v.es,
+        void *vp[] = {v.Srow, v.d_idx, v.d_dirty, v.px, v.py, v.pz, v.palpha, v.pflags, v.A,    v.es,
                       v.mu0,   v.mu1, v.munew, v.y, v.efind, v.efchg, v.rrms};
         for (void *p : vp)
             if (p) hipFree(p);
@@ -542,6 +547,20 @@ static int build_kvectors(mpmc_hip_ctx *c) {
         HIPCHK(hipMemcpy(c->d_kvec, kv.data(), kv.size() * sizeof(KVec), hipMemcpyHostToDevice));
     }
     c->kvec_valid = true;
+    return 0;
+}
+
+static int ensure_sym_scratch(SweepView &v) {
+    const size_t ncol = 3 * (size_t)v.nvpad;
+    const size_t need = ncol * (v.nvpad / kSymChunkAtoms + v.nvpad / kSymRowAtoms);
+    if (v.symcap < need) {
+        if (v.Srow) hipFree(v.Srow);
+        v.Srow = v.Zcol = nullptr;
+        v.symcap = 0;
+        HIPCHK(hipMalloc((void **)&v.Srow, need * sizeof(double)));
+        v.symcap = need;
+    }
+    v.Zcol = v.Srow + ncol * (v.nvpad / kSymChunkAtoms);
     return 0;
 }
 

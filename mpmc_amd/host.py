@@ -32,6 +32,7 @@ def load():
     lib.host_apply_config.argtypes = [vp, C.c_char_p]
     lib.host_mc_steps.argtypes = [vp, C.c_int]
     lib.host_set_device.argtypes = [vp, C.c_int]
+    lib.host_set_option.argtypes = [vp, C.c_char_p, C.c_int]
     lib.host_enable_timing.argtypes = [vp, C.c_int]
     lib.host_get_timings.argtypes = [vp, C.POINTER(engine.Timings)]
     lib.host_get_observables.argtypes = [vp, vp]
@@ -99,6 +100,11 @@ class HostSystem:
 
     def energy(self):
         return self.lib.energy(self.ptr)
+
+    def set_option(self, name, value):
+        """Engine A/B knob (mpmc_hip_set_option); the device context exists after the first energy()."""
+        if self.lib.host_set_option(self.ptr, name.encode(), int(value)) != 0:
+            raise engine.EngineError(engine.load().mpmc_hip_last_error().decode())
 
     def observables(self):
         out = np.zeros(8)

@@ -267,6 +267,27 @@ def test_incremental_amatrix_is_bit_identical_to_full_rebuild():
         e.close()
 
 
+def test_symmetric_sweep_matches_full_sweep():
+    """The default sweep reads only the upper triangle of A (each element used for both products);
+    option symmetric_sweep=0 streams the full matrix.  Same dipoles to rounding, both match the oracle."""
+    s = load("socmof_bssp_1228")
+    p = dict(FX["socmof_bssp_1228"]["params"], polar_palmo=1, polar_sor=1, polar_gamma=0.9, polar_rrms=1)
+    res = []
+    for sym in (2, 0):  # 2 = force the symmetric kernel even below its size threshold
+        e = engine.Engine(1228)
+        e.load_system(s, p)
+        e.set_option("symmetric_sweep", sym)
+        r = e.energy()
+        r.update(e.dipoles())
+        res.append(r)
+        e.close()
+    want = oracle.energy(s, p, want_vectors=True)
+    for r in res:
+        check_energies(r, want)
+        assert np.abs(r["mu"] - want["mu"]).max() <= 1e-10 * np.abs(want["mu"]).max()
+    assert np.abs(res[0]["mu"] - res[1]["mu"]).max() <= 1e-12 * np.abs(want["mu"]).max()
+
+
 def test_ragged_sizes_and_padding():
     """n not a multiple of the tile sizes, down to a single molecule."""
     for n in (5, 63, 65, 129, 257):
