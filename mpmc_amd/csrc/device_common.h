@@ -92,6 +92,61 @@ __device__ __forceinline__ void minimum_image(const DevBox &bx, double dx, doubl
     }
 }
 
+// Same arithmetic, but returns the SQUARED distances so that callers can apply the cutoff before
+// paying for an fp64 sqrt (most pairs of a big box lie outside it).  sqrt(r2)/sqrt(ri2) of the
+// returned values are bit-identical to r/rimg of minimum_image().
+__device__ __forceinline__ void minimum_image_sq(const DevBox &bx, double dx, double dy, double dz, double &r2o,
+                                                 double &ri2o, double &ox, double &oy, double &oz) {
+#pragma clang fp contract(off)
+    double i0 = bx.rb[0][0] * dx;
+    i0 = i0 + bx.rb[1][0] * dy;
+    i0 = i0 + bx.rb[2][0] * dz;
+    double i1 = bx.rb[0][1] * dx;
+    i1 = i1 + bx.rb[1][1] * dy;
+    i1 = i1 + bx.rb[2][1] * dz;
+    double i2 = bx.rb[0][2] * dx;
+    i2 = i2 + bx.rb[1][2] * dy;
+    i2 = i2 + bx.rb[2][2] * dz;
+    i0 = rint(i0);
+    i1 = rint(i1);
+    i2 = rint(i2);
+    double t0 = bx.b[0][0] * i0;
+    t0 = t0 + bx.b[1][0] * i1;
+    t0 = t0 + bx.b[2][0] * i2;
+    double t1 = bx.b[0][1] * i0;
+    t1 = t1 + bx.b[1][1] * i1;
+    t1 = t1 + bx.b[2][1] * i2;
+    double t2 = bx.b[0][2] * i0;
+    t2 = t2 + bx.b[1][2] * i1;
+    t2 = t2 + bx.b[2][2] * i2;
+    const double ex = dx - t0, ey = dy - t1, ez = dz - t2;
+    double r2 = dx * dx;
+    r2 = r2 + dy * dy;
+    r2 = r2 + dz * dz;
+    double ri2 = ex * ex;
+    ri2 = ri2 + ey * ey;
+    ri2 = ri2 + ez * ez;
+    r2o = r2;
+    if (ri2 != ri2) {  // isnan(ri) fallback, pairs.c:279 (sqrt(NaN) is NaN and ri2 is never negative)
+        ri2o = r2;
+        ox = dx;
+        oy = dy;
+        oz = dz;
+    } else {
+        ri2o = ri2;
+        ox = ex;
+        oy = ey;
+        oz = ez;
+    }
+}
+
+// Squared-distance pre-filter for the cutoff tests `rimg - 1e-12 < rc` / `!(rimg > rc)`: any pair that
+// passes those tests has rimg^2 below this bound, so pairs above it can be dropped before the sqrt.
+__device__ __forceinline__ double cutoff_prefilter_sq(double rc) {
+    const double h = rc + 1.0e-9;
+    return h * h;
+}
+
 // 64-lane butterfly sum; every lane ends with the total (fixed order => deterministic).
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

@@ -127,6 +127,8 @@ struct mpmc_hip_ctx {
     bool all_dirty = true;
     int opt_incremental = 1, opt_overlap = 1, opt_symmetric = 1;
     int *h_dirty = nullptr;         // pinned staging for dirty slots
+    double *h_stage = nullptr;      // pinned staging ring for update_atoms() coordinates
+    size_t stage_cap = 0, stage_used = 0;
     hipStream_t stream2 = nullptr;  // pair / reciprocal kernels overlap the polarization chain
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // scratch
@@ -302,6 +304,8 @@ extern "C" int mpmc_hip_create(mpmc_hip_ctx **out, int device, int max_atoms) {
     HIPCHK(hipHostMalloc((void **)&c->h_rank, np * sizeof(double), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&c->h_perm, np * sizeof(int), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&c->h_dirty, kMaxDirty * sizeof(int), hipHostMallocDefault));
+    c->stage_cap = 3 * 4096;
+    HIPCHK(hipHostMalloc((void **)&c->h_stage, c->stage_cap * sizeof(double), hipHostMallocDefault));
     c->ev_pool.resize(2 * 512);
     for (auto &e : c->ev_pool) HIPCHK(hipEventCreate(&e));
     HIPCHK(hipEventCreate(&c->ev_first));
@@ -337,6 +341,7 @@ extern "C" void mpmc_hip_destroy(mpmc_hip_ctx *c) {
     if (c->h_rank) hipHostFree(c->h_rank);
     if (c->h_perm) hipHostFree(c->h_perm);
     if (c->h_dirty) hipHostFree(c->h_dirty);
+    if (c->h_stage) hipHostFree(c->h_stage);
     for (auto &e : c->ev_pool) hipEventDestroy(e);
     if (c->ev_first) hipEventDestroy(c->ev_first);
     if (c->ev_last) hipEventDestroy(c->ev_last);
@@ -495,11 +500,28 @@ extern "C" int mpmc_hip_update_atoms(mpmc_hip_ctx *c, int first, int count, cons
     if (!x || !y || !z) return fail("MPMC_HIP: update_atoms: null array");
     HIPCHK(hipSetDevice(c->device));
     const size_t b = count * sizeof(double);
-    HIPCHK(hipMemcpyAsync(c->d_x + first, x, b, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->d_y + first, y, b, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->d_z + first, z, b, hipMemcpyHostToDevice, c->stream));
-    // pageable sources: make sure the copies are complete before the caller reuses its buffers
-    HIPCHK(hipStreamSynchronize(c->stream));
+    if ((size_t)(3 * count) <= c->stage_cap) {
+        // small delta (one molecule): stage in pinned memory so the copies are truly asynchronous and the
+        // caller's buffers are free at once; the ring is recycled after the next energy() has synchronised
+        if (c->stage_used + 3 * (size_t)count > c->stage_cap) {
+            HIPCHK(hipStreamSynchronize(c->stream));
+            c->stage_used = 0;
+        }
+        double *s = c->h_stage + c->stage_used;
+        memcpy(s, x, b);
+        memcpy(s + count, y, b);
+        memcpy(s + 2 * count, z, b);
+        c->stage_used += 3 * (size_t)count;
+        HIPCHK(hipMemcpyAsync(c->d_x + first, s, b, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->d_y + first, s + count, b, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->d_z + first, s + 2 * count, b, hipMemcpyHostToDevice, c->stream));
+    } else {
+        HIPCHK(hipMemcpyAsync(c->d_x + first, x, b, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->d_y + first, y, b, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->d_z + first, z, b, hipMemcpyHostToDevice, c->stream));
+        // pageable sources: make sure the copies are complete before the caller reuses its buffers
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
     if (!c->all_dirty) {
         if ((int)c->dirty_atoms.size() + count > 4 * kMaxDirty)
             c->all_dirty = true;
@@ -675,6 +697,7 @@ extern "C" int mpmc_hip_energy(mpmc_hip_ctx *c, mpmc_hip_result *out) {
     c->timed = true;
     c->dirty_atoms.clear();
     c->all_dirty = false;
+    c->stage_used = 0;
 
     const double *r = c->h_res;
     const double rd = r[R_RD_PAIR] + r[R_LRC];

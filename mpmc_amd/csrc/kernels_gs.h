@@ -277,16 +277,17 @@ __global__ __launch_bounds__(64) void rank_rmin_kernel(DevAtoms a, DevBox bx, do
     const int i = I * kWave + lane;
     const double xi = a.x[i], yi = a.y[i], zi = a.z[i];
     const bool pi = (a.alpha[i] != 0.0) && (a.flags[i] & kValid);
-    double rmin = kMAXVALUE;
+    double rmin2 = kMAXVALUE;
     for (int jj = 0; jj < kWave; ++jj) {
         const int j = jb + jj;
         if (!(pi && j > i && sal[jj] != 0.0 && (sfl[jj] & kValid))) continue;
-        double r, rimg, dx, dy, dz;
-        minimum_image(bx, xi - sx[jj], yi - sy[jj], zi - sz[jj], r, rimg, dx, dy, dz);
-        if (rimg < rmin) rmin = rimg;
+        double r2, ri2, dx, dy, dz;
+        minimum_image_sq(bx, xi - sx[jj], yi - sy[jj], zi - sz[jj], r2, ri2, dx, dy, dz);
+        if (ri2 < rmin2) rmin2 = ri2;
     }
-    rmin = wave_min(rmin);
-    if (lane == 0) out[0] = rmin;
+    rmin2 = wave_min(rmin2);
+    // sqrt is monotone and correctly rounded: sqrt(min ri2) == min sqrt(ri2)
+    if (lane == 0) out[0] = (rmin2 < kMAXVALUE) ? sqrt(rmin2) : kMAXVALUE;
 }
 
 __global__ __launch_bounds__(256) void reduce_min_kernel(const double *__restrict__ in, int count,

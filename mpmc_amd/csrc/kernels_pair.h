@@ -59,6 +59,7 @@ __global__ __launch_bounds__(64) void pair_rd_es_kernel(DevAtoms a, DevBox bx, P
     const double qi = a.q[i], epsi = a.eps[i], sigi = a.sig[i], mmi = a.molmass[i];
     const int moli = a.mol[i], fli = a.flags[i];
     const double rc = bx.cutoff;
+    const double rc2_hi = cutoff_prefilter_sq(rc);
     const double alpha = pp.ewald_alpha;
 
     double e_rd = 0.0, e_es = 0.0, e_intra = 0.0;
@@ -69,9 +70,12 @@ __global__ __launch_bounds__(64) void pair_rd_es_kernel(DevAtoms a, DevBox bx, P
         // pair (i<j), both real atoms, not frozen-frozen (lj.c:193, coulombic.c:165)
         bool act = (j > i) && (fli & kValid) && (flj & kValid) && !((fli & kFrozen) && (flj & kFrozen));
         if (!act) continue;
-        double r, rimg, dx, dy, dz;
-        minimum_image(bx, xi - t.x[jj], yi - t.y[jj], zi - t.z[jj], r, rimg, dx, dy, dz);
+        double r2, ri2, dx, dy, dz;
+        minimum_image_sq(bx, xi - t.x[jj], yi - t.y[jj], zi - t.z[jj], r2, ri2, dx, dy, dz);
         const bool same = (moli == t.mol[jj]);
+        const bool near = (ri2 <= rc2_hi);  // superset of every cutoff test below
+        if (!near && !same) continue;
+        const double rimg = near ? sqrt(ri2) : 2.0 * rc;
         const double epsj = t.eps[jj], sigj = t.sig[jj], qj = t.q[jj];
 
         // ---- repulsion/dispersion: lj.c:189-250, mixing pairs.c:200-211 (Lorentz-Berthelot)
@@ -138,6 +142,7 @@ __global__ __launch_bounds__(64) void pair_rd_es_kernel(DevAtoms a, DevBox bx, P
             } else if (same && qi != 0.0 && qj != 0.0) {
                 // charge-to-screen term of excluded (same-molecule) pairs; uses the UN-imaged r
                 // (coulombic.c:181-182).  es-excluded pairs with a zero charge contribute exactly 0.
+                const double r = sqrt(r2);
                 e_intra += qi * qj * erf(alpha * r) / r;
             }
         }

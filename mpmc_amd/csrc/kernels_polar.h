@@ -42,6 +42,7 @@ __global__ __launch_bounds__(64) void static_field_kernel(DevAtoms a, DevBox bx,
     const double xi = a.x[i], yi = a.y[i], zi = a.z[i];
     const int moli = a.mol[i], fli = a.flags[i];
     const double rc = bx.cutoff;
+    const double rc2_hi = cutoff_prefilter_sq(rc);
     const double rR = 1.0 / rc;
     double ex = 0.0, ey = 0.0, ez = 0.0;
 
@@ -61,8 +62,10 @@ __global__ __launch_bounds__(64) void static_field_kernel(DevAtoms a, DevBox bx,
             bool act = (j != i) && (fli & kValid) && (flj & kValid) && !((fli & kFrozen) && (flj & kFrozen)) &&
                        (moli != smol[jj]) && (qj != 0.0);
             if (!act) continue;
-            double r, rimg, dx, dy, dz;
-            minimum_image(bx, xi - sx[jj], yi - sy[jj], zi - sz[jj], r, rimg, dx, dy, dz);
+            double r2, ri2, dx, dy, dz;
+            minimum_image_sq(bx, xi - sx[jj], yi - sy[jj], zi - sz[jj], r2, ri2, dx, dy, dz);
+            if (!(ri2 <= rc2_hi)) continue;
+            const double rimg = sqrt(ri2);
             if ((rimg - kSMALL_dR < rc) && (rimg != 0.0)) {
                 double f;
                 if (MODE == kFieldBare) {
