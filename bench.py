@@ -90,7 +90,7 @@ def main():
     import torch
 
     dist = None
-    if world > 1:
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:  # under torchrun, also with a single rank
         import torch.distributed as dist
 
         torch.cuda.set_device(local_rank)

@@ -147,6 +147,15 @@ __device__ __forceinline__ double cutoff_prefilter_sq(double rc) {
     return h * h;
 }
 
+// Broadcast lane `src` (wave-uniform index) of a double through SGPRs: two v_readlane_b32 instead of
+// the two ds_bpermute_b32 (LDS crossbar round trips) that a generic __shfl costs.
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+    const int s = __builtin_amdgcn_readfirstlane(src);
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), s);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), s);
+    return __hiloint2double(hi, lo);
+}
+
 // 64-lane butterfly sum; every lane ends with the total (fixed order => deterministic).
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

@@ -24,9 +24,9 @@
 #include <vector>
 
 #include "device_common.h"
-#include "kernels_gs.h"
 #include "kernels_pair.h"
 #include "kernels_polar.h"
+#include "kernels_gs.h"
 #include "kernels_symv.h"
 
 using namespace mpmc;
@@ -137,6 +137,12 @@ struct mpmc_hip_ctx {
     double *d_perk = nullptr;       // [nk]
     KVec *d_kvec = nullptr;
     int nk = 0;
+    KVecF *d_kvecf = nullptr;  // k list weighted with polar_ewald_alpha (Ewald static field)
+    double2 *d_sf = nullptr;
+    int nkf = 0;
+    double kvecf_alpha = -1.0;
+    int kvecf_kmax = -1;
+    bool kvecf_valid = false;
     double *d_res = nullptr;  // R_COUNT doubles
     double *h_res = nullptr;  // pinned
     unsigned long long *h_err = nullptr;  // pinned, 1 word
@@ -295,7 +301,7 @@ extern "C" int mpmc_hip_create(mpmc_hip_ctx **out, int device, int max_atoms) {
     }
     const size_t ntile = np / 64;
     DALLOC(c->d_pairpart, ntile * ntile * kPairChannels, double);
-    const size_t nchunk_max = std::max<size_t>(1, np / 64);
+    const size_t nchunk_max = std::max<size_t>(1, np / 64) + 16;  // + k-chunk slots of the Ewald field
     DALLOC(c->d_fieldpart, nchunk_max * 3 * np, double);
     DALLOC(c->d_res, R_COUNT, double);
 #undef DALLOC
@@ -324,7 +330,7 @@ extern "C" void mpmc_hip_destroy(mpmc_hip_ctx *c) {
     void *dptrs[] = {c->d_x,   c->d_y,     c->d_z,     c->d_q,    c->d_alpha, c->d_eps,      c->d_sig,
                      c->d_molmass, c->d_mol, c->d_flags, c->d_es, c->d_mu,    c->d_efind,    c->d_efchg,
                      c->d_tmp3, c->d_rank, c->d_errmax, c->d_pairpart, c->d_fieldpart, c->d_perk, c->d_kvec,
-                     c->d_res};
+                     c->d_res,  c->d_kvecf, c->d_sf};
     for (void *p : dptrs)
         if (p) hipFree(p);
     for (SweepView &v : c->view) {
@@ -365,11 +371,11 @@ extern "C" int mpmc_hip_set_params(mpmc_hip_ctx *c, const mpmc_hip_params *p) {
             return fail("MPMC_HIP: polar_max_iter must be > 0 when polar_precision is 0");
         if (p->polar_sor && p->polar_esor) return fail("MPMC_HIP: cannot specify both SOR and ESOR SCF methods");
         if (p->polar_gamma < 0.0) return fail("MPMC_HIP: invalid Pre-cond/SOR/ESOR gamma set");
-        if (p->polar_ewald) return fail("MPMC_HIP: polar_ewald static field is not implemented yet");
     }
     if (p->polar_damp != c->par.polar_damp) c->all_dirty = true;
     c->par = *p;
     c->have_params = true;
+    c->kvecf_valid = false;
     c->kvec_valid = false;
     return 0;
 }
@@ -416,6 +422,7 @@ extern "C" int mpmc_hip_set_box(mpmc_hip_ctx *c, const double basis[9], double p
     c->cutoff = cutoff;
     c->volume = vol;
     c->have_box = true;
+    c->kvecf_valid = false;
     c->kvec_valid = false;
     c->lrc_valid = false;
     c->all_dirty = true;
@@ -569,6 +576,46 @@ static int build_kvectors(mpmc_hip_ctx *c) {
         HIPCHK(hipMemcpy(c->d_kvec, kv.data(), kv.size() * sizeof(KVec), hipMemcpyHostToDevice));
     }
     c->kvec_valid = true;
+    return 0;
+}
+
+// k list of the Ewald static field: same hemisphere as coulombic_reciprocal, weights with polar_ewald_alpha
+static int build_field_kvectors(mpmc_hip_ctx *c) {
+    const int kmax = c->par.ewald_kmax;
+    const double ea = c->polar_ewald_alpha;
+    if (c->d_kvecf && c->kvecf_alpha == ea && c->kvecf_kmax == kmax && c->kvecf_valid) return 0;
+    std::vector<KVecF> kv;
+    for (int l0 = 0; l0 <= kmax; l0++)
+        for (int l1 = (!l0 ? 0 : -kmax); l1 <= kmax; l1++)
+            for (int l2 = ((!l0 && !l1) ? 1 : -kmax); l2 <= kmax; l2++) {
+                if (l0 * l0 + l1 * l1 + l2 * l2 > kmax * kmax) continue;
+                const int l[3] = {l0, l1, l2};
+                double k[3];
+                for (int p = 0; p < 3; p++) {
+                    k[p] = 0;
+                    for (int q = 0; q < 3; q++) k[p] += 2.0 * kPI * c->recip[p][q] * l[q];
+                }
+                const double k2 = k[0] * k[0] + k[1] * k[1] + k[2] * k[2];
+                KVecF v;
+                v.kx = k[0];
+                v.ky = k[1];
+                v.kz = k[2];
+                v.w = std::exp(-k2 / (4.0 * ea * ea)) / k2;
+                kv.push_back(v);
+            }
+    if (c->d_kvecf) hipFree(c->d_kvecf);
+    if (c->d_sf) hipFree(c->d_sf);
+    c->d_kvecf = nullptr;
+    c->d_sf = nullptr;
+    c->nkf = (int)kv.size();
+    if (c->nkf > 0) {
+        HIPCHK(hipMalloc((void **)&c->d_kvecf, kv.size() * sizeof(KVecF)));
+        HIPCHK(hipMalloc((void **)&c->d_sf, kv.size() * sizeof(double2)));
+        HIPCHK(hipMemcpy(c->d_kvecf, kv.data(), kv.size() * sizeof(KVecF), hipMemcpyHostToDevice));
+    }
+    c->kvecf_alpha = ea;
+    c->kvecf_kmax = kmax;
+    c->kvecf_valid = true;
     return 0;
 }
 

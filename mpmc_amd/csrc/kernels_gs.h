@@ -111,7 +111,7 @@ __global__ __launch_bounds__(64) void gs_solve_block_kernel(const double *__rest
                 m1 = al * (e1 + y1);
                 m2 = al * (e2 + y2);
             }
-            const double bx = __shfl(m0, j, 64), by = __shfl(m1, j, 64), bz = __shfl(m2, j, 64);
+            const double bx = readlane_f64(m0, j), by = readlane_f64(m1, j), bz = readlane_f64(m2, j);
             if (lane > j) {
                 // T_lj = T_jl (symmetric 3x3 block): y_l[p] -= sum_q T[p][q] mu_j[q]; T is symmetric in p,q
                 y0 -= t[d][0] * bx + t[d][1] * by + t[d][2] * bz;
@@ -301,18 +301,21 @@ __global__ __launch_bounds__(256) void reduce_min_kernel(const double *__restric
     if (threadIdx.x == 0) out[0] = fmin(fmin(s[0], s[1]), fmin(s[2], s[3]));
 }
 
-// i-centric neighbour count; grid = npad/64, block = 64 (lane = atom i, all j staged via LDS).
-__global__ __launch_bounds__(64) void rank_count_kernel(DevAtoms a, const double *__restrict__ rmin_ptr,
-                                                         double *__restrict__ rank) {
+// i-centric neighbour count.  grid = (nchunk [j chunks], npad/64 [i tiles]), block = 64 (lane = atom i);
+// counts are integers, so the per-chunk partial counts are combined with integer atomics (exact and
+// order-independent) into cnt[], which count_to_rank_kernel converts to the double rank_metric.
+__global__ __launch_bounds__(64) void rank_count_kernel(DevAtoms a, const double *__restrict__ rmin_ptr, int chunk,
+                                                         unsigned int *__restrict__ cnt) {
     const int lane = threadIdx.x;
-    const int i = blockIdx.x * kWave + lane;
+    const int i = blockIdx.y * kWave + lane;
     __shared__ double sx[kWave], sy[kWave], sz[kWave], sal[kWave];
     __shared__ int sfl[kWave];
     const double lim = rmin_ptr[0] * 1.5;
     const double xi = a.x[i], yi = a.y[i], zi = a.z[i];
     const bool pi = (a.alpha[i] != 0.0) && (a.flags[i] & kValid);
-    double cnt = 0.0;
-    for (int jb = 0; jb < a.npad; jb += kWave) {
+    unsigned int n = 0;
+    const int jbeg = blockIdx.x * chunk;
+    for (int jb = jbeg; jb < jbeg + chunk && jb < a.npad; jb += kWave) {
         __syncthreads();
         sx[lane] = a.x[jb + lane];
         sy[lane] = a.y[jb + lane];
@@ -323,10 +326,16 @@ __global__ __launch_bounds__(64) void rank_count_kernel(DevAtoms a, const double
         for (int jj = 0; jj < kWave; ++jj) {
             const int j = jb + jj;
             if (!(pi && j != i && sal[jj] != 0.0 && (sfl[jj] & kValid))) continue;
-            if (plain_distance(xi - sx[jj], yi - sy[jj], zi - sz[jj]) <= lim) cnt += 1.0;
+            if (plain_distance(xi - sx[jj], yi - sy[jj], zi - sz[jj]) <= lim) n += 1u;
         }
     }
-    rank[i] = cnt;
+    if (n) atomicAdd(cnt + i, n);
+}
+
+__global__ __launch_bounds__(256) void count_to_rank_kernel(int npad, const unsigned int *__restrict__ cnt,
+                                                             double *__restrict__ rank) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < npad) rank[i] = (double)cnt[i];
 }
 
 }  // namespace mpmc

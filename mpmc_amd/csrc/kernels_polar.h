@@ -22,7 +22,7 @@ namespace mpmc {
 // pairs beyond the cutoff (inclusive within 1e-12).
 // grid = (nchunk [x], npad/64 [y]); block = 64.  part layout [chunk][3][npad].
 // ---------------------------------------------------------------------------------------------
-enum FieldMode { kFieldBare = 0, kFieldWolf0 = 1, kFieldWolfA = 2 };
+enum FieldMode { kFieldBare = 0, kFieldWolf0 = 1, kFieldWolfA = 2, kFieldEwald = 3 };
 
 struct FieldParams {
     double wolf_alpha;
@@ -40,6 +40,7 @@ __global__ __launch_bounds__(64) void static_field_kernel(DevAtoms a, DevBox bx,
     __shared__ int smol[kWave], sfl[kWave];
 
     const double xi = a.x[i], yi = a.y[i], zi = a.z[i];
+    const double qi = a.q[i];
     const int moli = a.mol[i], fli = a.flags[i];
     const double rc = bx.cutoff;
     const double rc2_hi = cutoff_prefilter_sq(rc);
@@ -60,13 +61,28 @@ __global__ __launch_bounds__(64) void static_field_kernel(DevAtoms a, DevBox bx,
             const int flj = sfl[jj];
             const double qj = sq[jj];
             bool act = (j != i) && (fli & kValid) && (flj & kValid) && !((fli & kFrozen) && (flj & kFrozen)) &&
-                       (moli != smol[jj]) && (qj != 0.0);
+                       (qj != 0.0);
+            // bare / Wolf fields skip same-molecule pairs (thole_field.c:50,96); the Ewald real term keeps
+            // them and gives them the screening form instead (polar_ewald.c:52-60)
+            if (MODE != kFieldEwald) act = act && (moli != smol[jj]);
             if (!act) continue;
             double r2, ri2, dx, dy, dz;
             minimum_image_sq(bx, xi - sx[jj], yi - sy[jj], zi - sz[jj], r2, ri2, dx, dy, dz);
             if (!(ri2 <= rc2_hi)) continue;
             const double rimg = sqrt(ri2);
-            if ((rimg - kSMALL_dR < rc) && (rimg != 0.0)) {
+            if (MODE == kFieldEwald) {
+                // real_term(), polar_ewald.c:38-80: exclusion = same molecule OR either charge zero
+                // (pairs.c:61-76), cutoff test is a plain r > rc
+                if ((rimg > rc) || (rimg == 0.0)) continue;
+                const double al = fp.wolf_alpha;  // = polar_ewald_alpha
+                const double r2i = rimg * rimg;
+                const double g = 2.0 * al * kOneOverSqrtPi * exp(-al * al * r2i) * rimg;
+                const bool excl = (moli == smol[jj]) || (qi == 0.0);
+                const double f = (excl ? (g - erf(al * rimg)) / (rimg * r2i) : (g + erfc(al * rimg)) / (r2i * rimg)) * qj;
+                ex += f * dx;
+                ey += f * dy;
+                ez += f * dz;
+            } else if ((rimg - kSMALL_dR < rc) && (rimg != 0.0)) {
                 double f;
                 if (MODE == kFieldBare) {
                     f = qj / (rimg * rimg * rimg);
@@ -90,6 +106,64 @@ __global__ __launch_bounds__(64) void static_field_kernel(DevAtoms a, DevBox bx,
     part[base + i] = ex;
     part[base + a.npad + i] = ey;
     part[base + 2 * (size_t)a.npad + i] = ez;
+}
+
+// Reciprocal part of the Ewald static field (recip_term(), polar_ewald.c:85-132):
+//   E_i = (8 pi / V) sum_k  k/k^2 e^{-k^2/4a^2} [ sin(k.r_i) F1_k - cos(k.r_i) F2_k ],
+//   F1_k = sum_a q_a cos(k.r_a), F2_k = sum_a q_a sin(k.r_a) over ALL atoms (frozen included).
+// Structure factors: one block per k (below).  Field: lane = atom, the k list is split into chunks
+// (grid.x) whose partial fields land in extra slots of the static-field partial buffer.
+struct KVecF {
+    double kx, ky, kz, w;  // w = exp(-k^2/4a^2)/k^2
+};
+
+__global__ __launch_bounds__(256) void ewald_field_sf_kernel(DevAtoms a, const KVecF *__restrict__ kv,
+                                                              double2 *__restrict__ sf) {
+    const KVecF k = kv[blockIdx.x];
+    double re = 0.0, im = 0.0;
+    for (int i = threadIdx.x; i < a.n; i += blockDim.x) {
+        const double q = a.q[i];
+        if (q == 0.0) continue;
+        double s, c;
+        sincos(k.kx * a.x[i] + k.ky * a.y[i] + k.kz * a.z[i], &s, &c);
+        re += q * c;
+        im += q * s;
+    }
+    re = wave_sum(re);
+    im = wave_sum(im);
+    __shared__ double sre[4], sim[4];
+    if ((threadIdx.x & 63) == 0) {
+        sre[threadIdx.x >> 6] = re;
+        sim[threadIdx.x >> 6] = im;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        sf[blockIdx.x] = make_double2((sre[0] + sre[1]) + (sre[2] + sre[3]), (sim[0] + sim[1]) + (sim[2] + sim[3]));
+}
+
+// grid = (nkchunk, npad/64), block = 64; part slot = slot0 + blockIdx.x
+__global__ __launch_bounds__(64) void ewald_field_recip_kernel(DevAtoms a, const KVecF *__restrict__ kv,
+                                                                const double2 *__restrict__ sf, int nk, int kchunk,
+                                                                double scale, int slot0, double *__restrict__ part) {
+    const int i = blockIdx.y * kWave + threadIdx.x;
+    const double xi = a.x[i], yi = a.y[i], zi = a.z[i];
+    const bool valid = a.flags[i] & kValid;
+    double ex = 0.0, ey = 0.0, ez = 0.0;
+    const int k0 = blockIdx.x * kchunk, k1 = min(nk, k0 + kchunk);
+    for (int k = k0; k < k1; ++k) {
+        const KVecF v = kv[k];  // wave-uniform: scalar loads
+        const double2 f = sf[k];
+        double s, c;
+        sincos(v.kx * xi + v.ky * yi + v.kz * zi, &s, &c);
+        const double t = v.w * (s * f.x - c * f.y);
+        ex += v.kx * t;
+        ey += v.ky * t;
+        ez += v.kz * t;
+    }
+    const size_t base = (size_t)(slot0 + blockIdx.x) * 3 * a.npad;
+    part[base + i] = valid ? ex * scale : 0.0;
+    part[base + a.npad + i] = valid ? ey * scale : 0.0;
+    part[base + 2 * (size_t)a.npad + i] = valid ? ez * scale : 0.0;
 }
 
 // es[3i+p] = sum over chunks (fixed order) [+ accumulate into existing when add != 0]

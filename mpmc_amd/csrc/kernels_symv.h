@@ -79,9 +79,9 @@ __global__ __launch_bounds__(64) void symv_kernel(const double *__restrict__ A, 
         if (!diag) {
             // x of rows row, row+1, row+2 (wave-uniform index => readlane broadcast)
             const int l = 3 * ia;
-            const double x0 = (l < 64) ? __shfl(xr_lo, l, 64) : __shfl(xr_hi, l - 64, 64);
-            const double x1 = (l + 1 < 64) ? __shfl(xr_lo, l + 1, 64) : __shfl(xr_hi, l + 1 - 64, 64);
-            const double x2 = (l + 2 < 64) ? __shfl(xr_lo, l + 2, 64) : __shfl(xr_hi, l + 2 - 64, 64);
+            const double x0 = (l < 64) ? readlane_f64(xr_lo, l) : readlane_f64(xr_hi, l - 64);
+            const double x1 = (l + 1 < 64) ? readlane_f64(xr_lo, l + 1) : readlane_f64(xr_hi, l + 1 - 64);
+            const double x2 = (l + 2 < 64) ? readlane_f64(xr_lo, l + 2) : readlane_f64(xr_hi, l + 2 - 64);
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
                 z[u].x += m0[u].x * x0;

@@ -138,6 +138,9 @@ POLAR_VARIANTS = {
     "zodid": dict(polar_zodid=1),
     "rrms": dict(polar_max_iter=5, polar_rrms=1),
     "one_iter_ranked": dict(polar_max_iter=1, polar_gs_ranked=1, polar_palmo=1),
+    "polar_ewald": dict(polar_max_iter=4, polar_ewald=1),
+    "polar_ewald_alpha_gs": dict(polar_max_iter=3, polar_ewald=1, polar_ewald_alpha_set=1, polar_ewald_alpha=0.25,
+                                 polar_gs=1, ewald_kmax=5),
 }
 
 
@@ -160,6 +163,17 @@ def test_polarization_variants_1024(variant):
     if p.get("polar_gs_ranked"):
         assert np.array_equal(got["rank"], want["rank_metric"])
         assert np.array_equal(got["order"], want["ranked_array"])
+
+
+def test_polar_ewald_field_with_frozen_framework():
+    """Ewald static field (polar_ewald.c:38-174) on the MOF-5 + BSSP H2 fixture: frozen-frozen pairs are
+    skipped in the real term but every atom enters the structure factors."""
+    s = load("mof5_bssp_429")
+    p = dict(temperature=77.0, polarization=1, polar_damp=2.1304, polar_max_iter=4, polar_ewald=1)
+    got = run_engine(s, p, vectors=True)
+    want = oracle.energy(s, p, want_vectors=True)
+    check_energies(got, want)
+    assert np.abs(got["ef_static"] - want["ef_static"]).max() <= 1e-10 * np.abs(want["ef_static"]).max()
 
 
 @pytest.mark.parametrize("gs", [0, 1])
