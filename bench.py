@@ -105,6 +105,9 @@ def main():
     # host control stays in C: system_t + energy() + the NVT chain of host/ drive the engine through the C ABI
     chain = host.HostSystem(system, flags, device=local_rank, seed=args.seed + rank)
     avg = WalkerAverages(dist=dist, device=dev)
+    if os.environ.get("MPMC_GS_DEBUG"):
+        chain.energy()
+        chain.set_option("persistent_gs", int(os.environ["MPMC_GS_DEBUG"]))
     if args.full_sweep or args.full_rebuild:
         chain.energy()  # creates the device context
         chain.set_option("symmetric_sweep", 0 if args.full_sweep else 1)

@@ -113,7 +113,9 @@ void mpmc_hip_destroy(mpmc_hip_ctx *ctx);
  *   "overlap_streams"     (default 1): run the LJ/Ewald kernels on a second HIP stream beside the
  *                          polarization chain;
  *   "symmetric_sweep"     (default 1): Jacobi/Palmo sweeps read only the upper triangle of A and use
- *                          every element for both products (half the HBM bytes); 0 = full-matrix sweep. */
+ *                          every element for both products (half the HBM bytes); 0 = full-matrix sweep;
+ *   "persistent_gs"       (default 1): Gauss-Seidel lower-triangle phase as one persistent kernel
+ *                          (spine + owner workgroups); 0 = two launches per 64-atom block. */
 int mpmc_hip_set_option(mpmc_hip_ctx *ctx, const char *name, int value);
 
 void mpmc_hip_default_params(mpmc_hip_params *p);

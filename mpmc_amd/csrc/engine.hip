@@ -27,6 +27,7 @@
 #include "kernels_pair.h"
 #include "kernels_polar.h"
 #include "kernels_gs.h"
+#include "kernels_gs_persistent.h"
 #include "kernels_symv.h"
 
 using namespace mpmc;
@@ -103,6 +104,8 @@ struct SweepView {
     std::vector<int> slot_of_atom;  // atom index -> view slot, -1 if not in the view
     double *es = nullptr, *mu0 = nullptr, *mu1 = nullptr, *munew = nullptr, *y = nullptr, *efind = nullptr,
            *efchg = nullptr, *rrms = nullptr;
+    double *ypart = nullptr;     // [nb][192] persistent Gauss-Seidel hand-off buffer
+    unsigned *gsflags = nullptr; // [2 + nb]
     double *Srow = nullptr, *Zcol = nullptr;  // partial sums of the symmetric sweep
     size_t symcap = 0;
     std::vector<int> h_idx;
@@ -125,7 +128,8 @@ struct mpmc_hip_ctx {
     bool have_polar_result = false;
     std::vector<int> dirty_atoms;   // atoms moved by update_atoms() since the last energy()
     bool all_dirty = true;
-    int opt_incremental = 1, opt_overlap = 1, opt_symmetric = 1;
+    int opt_incremental = 1, opt_overlap = 1, opt_symmetric = 1, opt_persistent_gs = 1;
+    int num_cus = 256;
     int *h_dirty = nullptr;         // pinned staging for dirty slots
     double *h_stage = nullptr;      // pinned staging ring for update_atoms() coordinates
     size_t stage_cap = 0, stage_used = 0;
@@ -146,6 +150,8 @@ struct mpmc_hip_ctx {
     double *d_res = nullptr;  // R_COUNT doubles
     double *h_res = nullptr;  // pinned
     unsigned long long *h_err = nullptr;  // pinned, 1 word
+    unsigned *h_gserr = nullptr;          // pinned: error words of the persistent Gauss-Seidel kernel (2 views)
+    bool gs_used[2] = {false, false};
     double *h_rank = nullptr;             // pinned, max_npad
     int *h_perm = nullptr;                // pinned, max_npad
     std::vector<int> perm;                // final sweep order (all atoms, as ranked_array)
@@ -227,6 +233,8 @@ extern "C" int mpmc_hip_set_option(mpmc_hip_ctx *c, const char *name, int value)
         c->opt_overlap = value;
     else if (!strcmp(name, "symmetric_sweep"))
         c->opt_symmetric = value;
+    else if (!strcmp(name, "persistent_gs"))
+        c->opt_persistent_gs = value;
     else
         return fail("MPMC_HIP: set_option: unknown option '%s'", name);
     return 0;
@@ -259,6 +267,9 @@ extern "C" int mpmc_hip_create(mpmc_hip_ctx **out, int device, int max_atoms) {
     c->max_npad = round_up(max_atoms, 128);
     mpmc_hip_default_params(&c->par);
     const size_t np = (size_t)c->max_npad;
+    c->num_cus = prop.multiProcessorCount;
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(gs_persistent_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, kGsPersistLds));
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -298,6 +309,8 @@ extern "C" int mpmc_hip_create(mpmc_hip_ctx **out, int device, int max_atoms) {
         DALLOC(v.efind, 3 * np, double);
         DALLOC(v.efchg, 3 * np, double);
         DALLOC(v.rrms, np, double);
+        DALLOC(v.ypart, 3 * np, double);
+        DALLOC(v.gsflags, 2 + np / 64 + 2, unsigned);
     }
     const size_t ntile = np / 64;
     DALLOC(c->d_pairpart, ntile * ntile * kPairChannels, double);
@@ -307,6 +320,7 @@ extern "C" int mpmc_hip_create(mpmc_hip_ctx **out, int device, int max_atoms) {
 #undef DALLOC
     HIPCHK(hipHostMalloc((void **)&c->h_res, R_COUNT * sizeof(double), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&c->h_err, sizeof(unsigned long long), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&c->h_gserr, 2 * sizeof(unsigned), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&c->h_rank, np * sizeof(double), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&c->h_perm, np * sizeof(int), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&c->h_dirty, kMaxDirty * sizeof(int), hipHostMallocDefault));
@@ -334,7 +348,7 @@ extern "C" void mpmc_hip_destroy(mpmc_hip_ctx *c) {
     for (void *p : dptrs)
         if (p) hipFree(p);
     for (SweepView &v : c->view) {
-        void *vp[] = {v.Srow, v.d_idx, v.d_dirty, v.px, v.py, v.pz, v.palpha, v.pflags, v.A,    v.es,
+        void *vp[] = {v.Srow, v.ypart, v.gsflags, v.d_idx, v.d_dirty, v.px, v.py, v.pz, v.palpha, v.pflags, v.A,    v.es,
                       v.mu0,   v.mu1, v.munew, v.y, v.efind, v.efchg, v.rrms};
         for (void *p : vp)
             if (p) hipFree(p);
@@ -344,6 +358,7 @@ extern "C" void mpmc_hip_destroy(mpmc_hip_ctx *c) {
     if (c->ev_join) hipEventDestroy(c->ev_join);
     if (c->h_res) hipHostFree(c->h_res);
     if (c->h_err) hipHostFree(c->h_err);
+    if (c->h_gserr) hipHostFree(c->h_gserr);
     if (c->h_rank) hipHostFree(c->h_rank);
     if (c->h_perm) hipHostFree(c->h_perm);
     if (c->h_dirty) hipHostFree(c->h_dirty);
@@ -739,7 +754,15 @@ extern "C" int mpmc_hip_energy(mpmc_hip_ctx *c, mpmc_hip_result *out) {
     if (c->opt_overlap) hipStreamWaitEvent(c->stream, c->ev_join, 0);
     hipEventRecord(c->ev_last, c->stream);
     HIPCHK(hipMemcpyAsync(c->h_res, c->d_res, R_COUNT * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    c->h_gserr[0] = c->h_gserr[1] = 0;
+    for (int v = 0; v < 2; ++v)
+        if (c->gs_used[v])
+            HIPCHK(hipMemcpyAsync(c->h_gserr + v, c->view[v].gsflags + 1, sizeof(unsigned), hipMemcpyDeviceToHost,
+                                  c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    const bool gs_timeout = (c->h_gserr[0] | c->h_gserr[1]) != 0;
+    c->gs_used[0] = c->gs_used[1] = false;
+    if (gs_timeout) return fail("MPMC_HIP: persistent Gauss-Seidel kernel gave up waiting on a hand-off (spin limit)");
     HIPCHK(hipGetLastError());
     c->timed = true;
     c->dirty_atoms.clear();

@@ -1,0 +1,304 @@
+// kernels_gs_persistent.h -- the lower-triangle phase of the exact Gauss-Seidel sweep as ONE
+// persistent kernel (replaces the 2 launches per 64-atom block of kernels_gs.h).
+//
+// Workgroup 0 is the SPINE: it walks the blocks in order and runs the serial forward substitution.
+// Workgroups 1..G-1 are OWNERS of target blocks (t mod (G-1)): an owner accumulates
+//   ypart_t = y_upper_t - sum_{s <= t-2} T(t,s) mu_new_s
+// as the spine publishes mu_new_s, and hands ypart_t to the spine.  The spine adds the one
+// contribution nobody else can have ready in time, s = t-1, itself.
+//
+// The critical path per block is the 64-step in-wave chain plus two workgroup barriers; every HBM
+// access of the spine is taken off it: while wave 0 runs the chain of block t, waves 1-7 load the
+// neighbour tile T(t+1,t) and the diagonal tile of block t+1 into REGISTERS (neither
+// depends on the dipoles); after the chain they only multiply / copy to LDS.
+//
+// Cross-workgroup hand-offs follow the gfx950 recipe (cdna_hip_programming.md, Guideline 16):
+// payload written with agent-scope relaxed atomic stores (write-through, sc1), every storing wave
+// drains (s_waitcnt vmcnt(0)), workgroup barrier, ONE lane stores the flag; consumers poll that one
+// word with relaxed agent-scope loads (+ s_sleep), then read the payload with agent-scope loads, which
+// bypass the (never refreshed) L1.  Dependencies are acyclic (ydone[t] needs ready >= t-1, which
+// needs ydone[<= t-2]); every spin is bounded and raises an error word instead of hanging.
+// Results do not depend on placement or timing: each sum has a fixed order.
+#pragma once
+#include "device_common.h"
+#include "kernels_gs.h"
+
+namespace mpmc {
+
+struct GsPersist {
+    const double *A;
+    int lda, nb;
+    const double *alpha, *es;
+    double *y;        // in: upper-triangle part (gs_upper_kernel); out: E_induced at update time
+    double *mu_new;   // out
+    double *ypart;    // [nb][192]
+    unsigned *flags;  // [0] blocks solved, [1] error, [2 + t] ydone[t]; zeroed before every launch
+    int debug;        // timing experiments only: 2 = spine does not wait for owners (WRONG results)
+};
+
+constexpr int kGsPairs = kGsBlock * (kGsBlock - 1) / 2;       // 2016
+constexpr int kGsTileDoubles = kGsPairs * 6;                  // 12096
+constexpr int kGsPersistLds = (kGsTileDoubles + 3 * kGsBlock + 8 * 3 * kGsBlock + 8) * 8;
+constexpr unsigned kGsSpinLimit = 1u << 24;
+
+__device__ __forceinline__ int gs_row_offset(int j) { return j * (kGsBlock - 1) - j * (j - 1) / 2; }
+
+__device__ __forceinline__ void st_agent(double *p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_agent(const double *p) {
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p),
+                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// one lane polls until *flag >= target; false on timeout or when another workgroup raised the error word
+__device__ __forceinline__ bool spin_ge(unsigned *flag, unsigned target, unsigned *err) {
+    for (unsigned it = 0; it < kGsSpinLimit; ++it) {
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
+        if ((it & 63u) == 63u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return false;
+}
+
+// 6 unique elements of T_jl from row-block j (rows 3j..3j+2), columns 3l..3l+2
+__device__ __forceinline__ void load_tensor6(const double *r, size_t lda, double *t) {
+    t[0] = r[0];
+    t[1] = r[1];
+    t[2] = r[2];
+    t[3] = r[lda + 1];
+    t[4] = r[lda + 2];
+    t[5] = r[2 * lda + 2];
+}
+
+__device__ void gs_owner(const GsPersist &p, int first, int stride, double *lds) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double *smu = lds;                 // [192]
+    double *part = lds + 3 * kGsBlock; // [8][3][64]
+    __shared__ int s_ok;
+    unsigned known = 0;                // blocks known to be solved
+    for (int t = first; t < p.nb; t += stride) {
+        const int k = t * kGsBlock + lane;  // this lane's target atom
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+        for (int s = 0; s + 2 <= t; ++s) {
+            // tile loads first: they do not depend on the dipoles and hide behind the wait
+            double tt[8][6];
+            const double *base = p.A + (size_t)(3 * (s * kGsBlock + 8 * w)) * p.lda + 3 * (size_t)k;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) load_tensor6(base + (size_t)(3 * jj) * p.lda, (size_t)p.lda, tt[jj]);
+            if (known < (unsigned)(s + 1)) {
+                if (threadIdx.x == 0) {
+                    s_ok = spin_ge(p.flags, (unsigned)(s + 1), p.flags + 1) ? 1 : 0;
+                }
+                __syncthreads();
+                if (!s_ok) return;
+                known = (unsigned)(s + 1);
+            }
+            __syncthreads();  // smu free
+            if (threadIdx.x < 3 * kGsBlock) smu[threadIdx.x] = ld_agent(p.mu_new + 3 * s * kGsBlock + threadIdx.x);
+            __syncthreads();
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const double mx = smu[3 * (8 * w + jj)], my = smu[3 * (8 * w + jj) + 1], mz = smu[3 * (8 * w + jj) + 2];
+                a0 += tt[jj][0] * mx + tt[jj][1] * my + tt[jj][2] * mz;
+                a1 += tt[jj][1] * mx + tt[jj][3] * my + tt[jj][4] * mz;
+                a2 += tt[jj][2] * mx + tt[jj][4] * my + tt[jj][5] * mz;
+            }
+        }
+        __syncthreads();
+        part[(w * 3 + 0) * kGsBlock + lane] = a0;
+        part[(w * 3 + 1) * kGsBlock + lane] = a1;
+        part[(w * 3 + 2) * kGsBlock + lane] = a2;
+        __syncthreads();
+        if (w == 0) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                double sum = 0.0;
+#pragma unroll
+                for (int g = 0; g < 8; ++g) sum += part[(g * 3 + q) * kGsBlock + lane];
+                st_agent(p.ypart + (size_t)t * 3 * kGsBlock + 3 * lane + q, p.y[3 * k + q] - sum);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(p.flags + 2 + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+    }
+}
+
+__device__ void gs_spine(const GsPersist &p, double *lds) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    double *tile = lds;                                 // [12096] strictly-upper part of the diagonal tile
+    double *smu = lds + kGsTileDoubles;                 // [192] mu of the block just solved
+    double *part = smu + 3 * kGsBlock;                  // [7][3][64] neighbour partial sums
+    __shared__ int s_ok;
+    const size_t lda = (size_t)p.lda;
+
+    // what this thread prefetches for the NEXT block while wave 0 runs the chain
+    // waves 1-7 (448 helper threads): neighbour tensors T(j, l = lane of block t+1) for the sources
+    // j = g, g+7, g+14, ... (g = w-1), and 5 (4 for some) pairs of the next diagonal tile
+    double nreg[10][6];
+    double dreg[5][6];
+    // the (j, l > j) pairs of the diagonal tile this helper thread stages: idx = th + 448 q, row-major over j
+    int dj[5], dl[5];
+    {
+        const int th = (w >= 1 ? (w - 1) * 64 + lane : 0);
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            int jj = 0, rem = th + 448 * q;
+            while (jj < kGsBlock - 1 && rem >= kGsBlock - 1 - jj) {
+                rem -= kGsBlock - 1 - jj;
+                ++jj;
+            }
+            dj[q] = jj;
+            dl[q] = jj + 1 + rem;
+        }
+    }
+    auto prefetch = [&](int tn) {  // tn = block whose tiles are fetched
+        if (w >= 1 && tn >= 1) {
+            const double *base = p.A + (size_t)(3 * (tn - 1) * kGsBlock) * lda + 3 * (size_t)(tn * kGsBlock + lane);
+#pragma unroll
+            for (int jj = 0; jj < 10; ++jj) {
+                const int j = (w - 1) + 7 * jj;
+                if (j < kGsBlock) load_tensor6(base + (size_t)(3 * j) * lda, lda, nreg[jj]);
+            }
+        }
+        if (w >= 1) {
+            const int th = (w - 1) * 64 + lane;  // 0..447
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                const int idx = th + 448 * q;
+                if (idx < kGsPairs)
+                    load_tensor6(p.A + (size_t)(3 * (tn * kGsBlock + dj[q])) * lda + 3 * (size_t)(tn * kGsBlock + dl[q]), lda,
+                                 dreg[q]);
+            }
+        }
+    };
+
+    prefetch(0);
+    for (int t = 0; t < p.nb; ++t) {
+        // ---- [A] neighbour contribution of block t-1 (registers x smu), [B] diagonal tile -> LDS
+        if (w >= 1) {
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+            if (t >= 1) {
+#pragma unroll
+                for (int jj = 0; jj < 10; ++jj) {
+                    const int j = (w - 1) + 7 * jj;
+                    if (j < kGsBlock) {
+                        const double mx = smu[3 * j], my = smu[3 * j + 1], mz = smu[3 * j + 2];
+                        a0 += nreg[jj][0] * mx + nreg[jj][1] * my + nreg[jj][2] * mz;
+                        a1 += nreg[jj][1] * mx + nreg[jj][3] * my + nreg[jj][4] * mz;
+                        a2 += nreg[jj][2] * mx + nreg[jj][4] * my + nreg[jj][5] * mz;
+                    }
+                }
+            }
+            part[((w - 1) * 3 + 0) * kGsBlock + lane] = a0;
+            part[((w - 1) * 3 + 1) * kGsBlock + lane] = a1;
+            part[((w - 1) * 3 + 2) * kGsBlock + lane] = a2;
+            const int th = (w - 1) * 64 + lane;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                const int idx = th + 448 * q;
+                if (idx < kGsPairs) {
+                    const int j = dj[q], l = dl[q];
+                    const int wd = kGsBlock - 1 - j;
+                    double *dst = tile + (size_t)gs_row_offset(j) * 6 + (l - j - 1);
+#pragma unroll
+                    for (int e = 0; e < 6; ++e) dst[e * wd] = dreg[q][e];
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- everyone but wave 0: fetch the tiles of block t+1 while the chain runs
+        if (w != 0 && t + 1 < p.nb) prefetch(t + 1);
+
+        if (w == 0) {
+            if (lane == 0) s_ok = (p.debug == 2) ? 1 : (spin_ge(p.flags + 2 + t, 1u, p.flags + 1) ? 1 : 0);
+            // single wave: program order keeps the loads below behind the poll
+            const int k = t * kGsBlock + lane;
+            double y0 = 0.0, y1 = 0.0, y2 = 0.0;
+            const bool ok = __shfl(s_ok, 0, 64) != 0;
+            if (ok) {
+                y0 = ld_agent(p.ypart + (size_t)t * 3 * kGsBlock + 3 * lane);
+                y1 = ld_agent(p.ypart + (size_t)t * 3 * kGsBlock + 3 * lane + 1);
+                y2 = ld_agent(p.ypart + (size_t)t * 3 * kGsBlock + 3 * lane + 2);
+#pragma unroll
+                for (int g = 0; g < 7; ++g) {
+                    y0 -= part[(g * 3 + 0) * kGsBlock + lane];
+                    y1 -= part[(g * 3 + 1) * kGsBlock + lane];
+                    y2 -= part[(g * 3 + 2) * kGsBlock + lane];
+                }
+                const double al = p.alpha[k];
+                const double ae0 = al * p.es[3 * k], ae1 = al * p.es[3 * k + 1], ae2 = al * p.es[3 * k + 2];
+                // The chain is issue-bound (one wave, ~30 instructions per step), so it is fully unrolled:
+                // lane masks, LDS offsets and readlane indices become immediates.  A lane's y stops changing
+                // once its own step has passed, so its dipole al*(E + y) is simply evaluated after the loop;
+                // inside the loop every lane evaluates the candidate and lane j's value is broadcast.
+                // LDS reads of step j+1 are issued (unmasked: lanes <= j+1 read neighbouring, unused words of
+                // the tile) before the dependent arithmetic of step j, so their latency is off the chain.
+                double c[6];
+                {
+                    const double *tp = tile + (lane - 1);
+#pragma unroll
+                    for (int e = 0; e < 6; ++e) c[e] = tp[e * (kGsBlock - 1)];
+                }
+#pragma unroll
+                for (int j = 0; j < kGsBlock - 1; ++j) {
+                    double n[6] = {0, 0, 0, 0, 0, 0};
+                    if (j + 1 < kGsBlock - 1) {
+                        const int wd = kGsBlock - 2 - j;
+                        const double *tp = tile + gs_row_offset(j + 1) * 6 + (lane - j - 2);
+#pragma unroll
+                        for (int e = 0; e < 6; ++e) n[e] = tp[e * wd];
+                    }
+                    const double bx = readlane_f64(fma(al, y0, ae0), j);
+                    const double by = readlane_f64(fma(al, y1, ae1), j);
+                    const double bz = readlane_f64(fma(al, y2, ae2), j);
+                    if (lane > j) {
+                        y0 = fma(-c[0], bx, y0);
+                        y0 = fma(-c[1], by, y0);
+                        y0 = fma(-c[2], bz, y0);
+                        y1 = fma(-c[1], bx, y1);
+                        y1 = fma(-c[3], by, y1);
+                        y1 = fma(-c[4], bz, y1);
+                        y2 = fma(-c[2], bx, y2);
+                        y2 = fma(-c[4], by, y2);
+                        y2 = fma(-c[5], bz, y2);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 6; ++e) c[e] = n[e];
+                }
+                const double m0 = fma(al, y0, ae0), m1 = fma(al, y1, ae1), m2 = fma(al, y2, ae2);
+                smu[3 * lane] = m0;
+                smu[3 * lane + 1] = m1;
+                smu[3 * lane + 2] = m2;
+                st_agent(p.mu_new + 3 * k, m0);
+                st_agent(p.mu_new + 3 * k + 1, m1);
+                st_agent(p.mu_new + 3 * k + 2, m2);
+                p.y[3 * k] = y0;  // E_induced of the atom when it was updated (thole_iterative.c:44-46)
+                p.y[3 * k + 1] = y1;
+                p.y[3 * k + 2] = y2;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0)
+                    __hip_atomic_store(p.flags, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();
+        if (!s_ok) return;
+    }
+}
+
+// grid = G (2 <= G <= number of CUs, so that every workgroup is resident), block = 512 (8 waves: two
+// per SIMD leaves each thread 256 VGPRs, enough to hold the prefetched tiles without spilling),
+// dynamic LDS = kGsPersistLds
+__global__ __launch_bounds__(512) void gs_persistent_kernel(GsPersist p) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    if (blockIdx.x == 0)
+        gs_spine(p, lds);
+    else
+        gs_owner(p, (int)blockIdx.x - 1, (int)gridDim.x - 1, lds);
+}
+
+}  // namespace mpmc
