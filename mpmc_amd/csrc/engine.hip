@@ -65,7 +65,7 @@ extern "C" int mpmc_hip_device_count(void) {
 // ------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------
-constexpr int kMaxDirty = 64;  // more moved atoms than this => full A rebuild
+constexpr int kMaxDirty = 64;  // more moved atoms than this => full A rebuild (= DirtyList capacity)
 
 enum TimeClass { T_PAIR = 0, T_RECIP, T_FIELD, T_AMAT, T_SWEEP, T_PALMO, T_OTHER, T_NCLASS };
 
@@ -100,7 +100,7 @@ struct SweepView {
     double *A = nullptr;
     size_t Acap = 0;  // doubles
     bool A_valid = false;  // A matches the configuration as of the last energy() (minus `dirty` atoms)
-    int *d_dirty = nullptr;
+    int *d_slot = nullptr;  // device copy of slot_of_atom (padded with -1)
     std::vector<int> slot_of_atom;  // atom index -> view slot, -1 if not in the view
     double *es = nullptr, *mu0 = nullptr, *mu1 = nullptr, *munew = nullptr, *y = nullptr, *efind = nullptr,
            *efchg = nullptr, *rrms = nullptr;
@@ -130,6 +130,9 @@ struct mpmc_hip_ctx {
     bool all_dirty = true;
     int opt_incremental = 1, opt_overlap = 1, opt_symmetric = 1, opt_persistent_gs = 1;
     int num_cus = 256;
+    int opt_timing = 1;    // 0: no events, 1: sweep kernels + total only, 2: every kernel class
+    int opt_sym_mode = 0;  // bit 0: alternate sweep direction, bit 1: default-policy loads
+    int sweep_parity = 0;
     int *h_dirty = nullptr;         // pinned staging for dirty slots
     double *h_stage = nullptr;      // pinned staging ring for update_atoms() coordinates
     size_t stage_cap = 0, stage_used = 0;
@@ -208,7 +211,8 @@ struct ScopedTimer {
     TimeRec r;
     bool on;
     ScopedTimer(mpmc_hip_ctx *ctx, int cls, hipStream_t st = nullptr) : c(ctx), s(st ? st : ctx->stream), on(false) {
-        if (c->ev_next + 2 <= c->ev_pool.size()) {
+        const bool wanted = c->opt_timing >= 2 || (c->opt_timing == 1 && cls == 4 /* T_SWEEP */);
+        if (wanted && c->ev_next + 2 <= c->ev_pool.size()) {
             r.cls = cls;
             r.a = c->ev_pool[c->ev_next++];
             r.b = c->ev_pool[c->ev_next++];
@@ -233,6 +237,10 @@ extern "C" int mpmc_hip_set_option(mpmc_hip_ctx *c, const char *name, int value)
         c->opt_overlap = value;
     else if (!strcmp(name, "symmetric_sweep"))
         c->opt_symmetric = value;
+    else if (!strcmp(name, "timing"))
+        c->opt_timing = value;
+    else if (!strcmp(name, "sym_mode"))
+        c->opt_sym_mode = value;
     else if (!strcmp(name, "persistent_gs"))
         c->opt_persistent_gs = value;
     else
@@ -295,7 +303,7 @@ extern "C" int mpmc_hip_create(mpmc_hip_ctx **out, int device, int max_atoms) {
     for (SweepView &v : c->view) {
         v.cap = (int)np;
         DALLOC(v.d_idx, np, int);
-        DALLOC(v.d_dirty, kMaxDirty, int);
+        DALLOC(v.d_slot, np, int);
         DALLOC(v.px, np, double);
         DALLOC(v.py, np, double);
         DALLOC(v.pz, np, double);
@@ -348,7 +356,7 @@ extern "C" void mpmc_hip_destroy(mpmc_hip_ctx *c) {
     for (void *p : dptrs)
         if (p) hipFree(p);
     for (SweepView &v : c->view) {
-        void *vp[] = {v.Srow, v.ypart, v.gsflags, v.d_idx, v.d_dirty, v.px, v.py, v.pz, v.palpha, v.pflags, v.A,    v.es,
+        void *vp[] = {v.Srow, v.ypart, v.gsflags, v.d_idx, v.d_slot, v.px, v.py, v.pz, v.palpha, v.pflags, v.A,    v.es,
                       v.mu0,   v.mu1, v.munew, v.y, v.efind, v.efchg, v.rrms};
         for (void *p : vp)
             if (p) hipFree(p);
@@ -507,6 +515,11 @@ extern "C" int mpmc_hip_upload(mpmc_hip_ctx *c, int n, const double *x, const do
     v0.nvpad = std::max(128, round_up(v0.nv, 128));
     v0.slot_of_atom.assign(n, -1);
     for (int k = 0; k < v0.nv; ++k) v0.slot_of_atom[v0.h_idx[k]] = k;
+    {
+        std::vector<int> hs(npad, -1);
+        std::copy(v0.slot_of_atom.begin(), v0.slot_of_atom.end(), hs.begin());
+        HIPCHK(hipMemcpy(v0.d_slot, hs.data(), npad * sizeof(int), hipMemcpyHostToDevice));
+    }
     c->all_dirty = true;
     c->dirty_atoms.clear();
     c->view[0].A_valid = c->view[1].A_valid = false;

@@ -291,12 +291,15 @@ __global__ __launch_bounds__(64) void build_amatrix_kernel(DevAtoms a, DevBox bx
 // the reference's O(N^2) rebuild (thole_matrix.c:58-143 every step).  Every rewritten entry is the
 // same function of the same coordinates as in a full build, hence bit-identical to it.
 // grid = (nvpad/128 [column tiles], ndirty); block = 64.
-__global__ __launch_bounds__(64) void update_amatrix_kernel(DevAtoms a, DevBox bx, double damp,
-                                                             const int *__restrict__ dirty,
+struct DirtyList {  // passed by value in the kernel arguments: no H2D copy on the step's critical path
+    int slot[64];
+};
+
+__global__ __launch_bounds__(64) void update_amatrix_kernel(DevAtoms a, DevBox bx, double damp, DirtyList dirty,
                                                              double *__restrict__ A, int lda) {
     const int lane = threadIdx.x;
     const int j0 = blockIdx.x * 128 + 2 * lane;
-    const int i = dirty[blockIdx.y];
+    const int i = dirty.slot[blockIdx.y];
     const double xi = a.x[i], yi = a.y[i], zi = a.z[i], ali = a.alpha[i];
     const bool vi = a.flags[i] & kValid;
     const double2 xj = *reinterpret_cast<const double2 *>(a.x + j0);
@@ -483,6 +486,49 @@ __global__ __launch_bounds__(256) void init_dipoles_kernel(int npad, const doubl
         ef_change[3 * i + p] = 0.0;
     }
     rrms[i] = 0.0;
+}
+
+// Same, fused with the gather of E_static into the sweep view and the reset of the per-call
+// convergence words (one launch instead of four).
+__global__ __launch_bounds__(256) void init_view_kernel(int nv, int nvpad, const int *__restrict__ idx,
+                                                         const double *__restrict__ alpha,
+                                                         const double *__restrict__ es_full, double scale,
+                                                         double *__restrict__ es, double *__restrict__ mu,
+                                                         double *__restrict__ ef_induced,
+                                                         double *__restrict__ ef_change, double *__restrict__ rrms,
+                                                         unsigned long long *__restrict__ errmax) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < 256) errmax[k] = 0ull;
+    if (k >= nvpad) return;
+    const double al = alpha[k];
+    const int src = (k < nv) ? idx[k] : -1;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const double e = (src >= 0) ? es_full[3 * src + p] : 0.0;
+        es[3 * k + p] = e;
+        mu[3 * k + p] = al * e * scale;
+        ef_induced[3 * k + p] = 0.0;
+        ef_change[3 * k + p] = 0.0;
+    }
+    rrms[k] = 0.0;
+}
+
+// mu / E_ind / dE_ind back to atom order in one launch (zeros on sites outside the view)
+__global__ __launch_bounds__(256) void scatter_results_kernel(int npad, const int *__restrict__ slot_of_atom,
+                                                               const double *__restrict__ vmu,
+                                                               const double *__restrict__ vefind,
+                                                               const double *__restrict__ vefchg,
+                                                               double *__restrict__ mu, double *__restrict__ efind,
+                                                               double *__restrict__ efchg) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npad) return;
+    const int s = slot_of_atom[i];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        mu[3 * i + p] = (s >= 0) ? vmu[3 * s + p] : 0.0;
+        efind[3 * i + p] = (s >= 0) ? vefind[3 * s + p] : 0.0;
+        efchg[3 * i + p] = (s >= 0) ? vefchg[3 * s + p] : 0.0;
+    }
 }
 
 // Divergence fallback (thole_iterative.c:199-210): mu = alpha*E_static, dE_ind = 0.

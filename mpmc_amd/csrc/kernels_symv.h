@@ -27,10 +27,18 @@ constexpr int kSymRowAtoms = 32;     // rows per unit = 96
 // grid = (nchunk, nrowblock); block = 64.  Single-wave workgroups: ~5.5 units per CU at N = 4096, which
 // the dispatcher balances to within one unit (4-wave workgroups covering a whole 128x128-atom tile
 // left 95 of 256 CUs with twice the bytes of the others: 93 us instead of 71 us per sweep).
+//
+// Infinity-Cache reuse across sweeps: the triangle (414 MB at nv = 3264) does not fit the 256 MB L3,
+// but consecutive sweeps of one energy() read the same matrix.  With `reverse` set on every other sweep
+// the units are visited in the opposite order, so a sweep starts on the data the previous one touched
+// last (still resident); POLICY selects non-temporal (0) or default-policy (1) loads for that.
+template <int POLICY>
 __global__ __launch_bounds__(64) void symv_kernel(const double *__restrict__ A, int lda, int nvpad,
                                                    const double *__restrict__ x, double *__restrict__ Srow,
-                                                   double *__restrict__ Zcol) {
-    const int ch = blockIdx.x, rb = blockIdx.y, lane = threadIdx.x;
+                                                   double *__restrict__ Zcol, int reverse) {
+    const int lane = threadIdx.x;
+    const int ch = reverse ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
+    const int rb = reverse ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;
     const int dch = rb / (kSymChunkAtoms / kSymRowAtoms);
     if (ch < dch) return;
     const bool diag = (ch == dch);
@@ -55,9 +63,15 @@ __global__ __launch_bounds__(64) void symv_kernel(const double *__restrict__ A, 
         double2 m0[3], m1[3], m2[3];
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
-            m0[u] = stream_load2(a0 + 128 * u);
-            m1[u] = stream_load2(a0 + lda + 128 * u);
-            m2[u] = stream_load2(a0 + 2 * (size_t)lda + 128 * u);
+            if (POLICY == 0) {
+                m0[u] = stream_load2(a0 + 128 * u);
+                m1[u] = stream_load2(a0 + lda + 128 * u);
+                m2[u] = stream_load2(a0 + 2 * (size_t)lda + 128 * u);
+            } else {
+                m0[u] = *reinterpret_cast<const double2 *>(a0 + 128 * u);
+                m1[u] = *reinterpret_cast<const double2 *>(a0 + lda + 128 * u);
+                m2[u] = *reinterpret_cast<const double2 *>(a0 + 2 * (size_t)lda + 128 * u);
+            }
         }
         double s0 = 0.0, s1 = 0.0, s2 = 0.0;
         const unsigned own = (unsigned)row;  // first column of this atom's own 3x3 block

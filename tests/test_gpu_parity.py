@@ -328,6 +328,7 @@ def test_timings_available():
     s = synth.s_pol(1024)
     eng = engine.Engine(1024)
     eng.load_system(s, synth.FLAGS_POL_JACOBI)
+    eng.set_option("timing", 2)
     eng.energy()
     t = eng.timings()
     eng.close()
