@@ -30,6 +30,9 @@ struct DevBox {
     double rb[3][3];  // reciprocal_basis (matrix inverse), reference src/energy/pbc.c:47-63
     double cutoff;
     double volume;
+    float fb[3][3];   // single-precision copies for the cutoff pre-filter
+    float frb[3][3];
+    float rc2_pre;    // (cutoff + 0.01 A)^2
 };
 
 // SoA view of the configuration resident in HBM.  All arrays have npad entries
@@ -138,6 +141,28 @@ __device__ __forceinline__ void minimum_image_sq(const DevBox &bx, double dx, do
         oy = ey;
         oz = ez;
     }
+}
+
+// Cheap single-precision screen for the cutoff-limited pair kernels: in a 40 A box with an 8 A cutoff
+// 97 % of the pairs lie outside the cutoff, and the exact fp64 minimum image (no FMA contraction, ~46
+// fp64 operations) is what those kernels spend their time on.  The screen evaluates the same minimum
+// image in fp32 (~30 operations at twice the rate) and keeps every pair within cutoff + 0.01 A; fp32
+// rounding of coordinates below ~100 A moves a distance by < 1e-4 A, and if fp32 picks the other image
+// of a tie both images are equidistant to that accuracy, so no pair the exact test accepts is lost.
+// Pairs that pass are decided by the exact fp64 path as before, so results are unchanged.
+__device__ __forceinline__ bool prefilter_within(const DevBox &bx, double dxd, double dyd, double dzd) {
+    const float dx = (float)dxd, dy = (float)dyd, dz = (float)dzd;
+    float i0 = bx.frb[0][0] * dx + bx.frb[1][0] * dy + bx.frb[2][0] * dz;
+    float i1 = bx.frb[0][1] * dx + bx.frb[1][1] * dy + bx.frb[2][1] * dz;
+    float i2 = bx.frb[0][2] * dx + bx.frb[1][2] * dy + bx.frb[2][2] * dz;
+    i0 = rintf(i0);
+    i1 = rintf(i1);
+    i2 = rintf(i2);
+    const float ex = dx - (bx.fb[0][0] * i0 + bx.fb[1][0] * i1 + bx.fb[2][0] * i2);
+    const float ey = dy - (bx.fb[0][1] * i0 + bx.fb[1][1] * i1 + bx.fb[2][1] * i2);
+    const float ez = dz - (bx.fb[0][2] * i0 + bx.fb[1][2] * i1 + bx.fb[2][2] * i2);
+    const float r2 = ex * ex + ey * ey + ez * ez;
+    return !(r2 > bx.rc2_pre);  // NaN passes: the exact path handles it
 }
 
 // Squared-distance pre-filter for the cutoff tests `rimg - 1e-12 < rc` / `!(rimg > rc)`: any pair that

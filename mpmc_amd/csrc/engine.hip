@@ -200,6 +200,12 @@ static DevBox dev_box(const mpmc_hip_ctx *c) {
         }
     b.cutoff = c->cutoff;
     b.volume = c->volume;
+    for (int p = 0; p < 3; ++p)
+        for (int q = 0; q < 3; ++q) {
+            b.fb[p][q] = (float)c->basis[p][q];
+            b.frb[p][q] = (float)c->recip[p][q];
+        }
+    b.rc2_pre = (float)((c->cutoff + 0.01) * (c->cutoff + 0.01));
     return b;
 }
 

@@ -64,15 +64,23 @@ __global__ __launch_bounds__(64) void pair_rd_es_kernel(DevAtoms a, DevBox bx, P
 
     double e_rd = 0.0, e_es = 0.0, e_intra = 0.0;
 
+    // Phase 1: flag tests + fp32 distance screen -> candidate bit per partner; phase 2: exact path for
+    // the set bits only (see static_field_kernel for why the loops are split).
+    unsigned long long cand = 0ull;
     for (int jj = 0; jj < kWave; ++jj) {
         const int j = J * kWave + jj;
         const int flj = t.flags[jj];
         // pair (i<j), both real atoms, not frozen-frozen (lj.c:193, coulombic.c:165)
-        bool act = (j > i) && (fli & kValid) && (flj & kValid) && !((fli & kFrozen) && (flj & kFrozen));
-        if (!act) continue;
+        const bool act = (j > i) && (fli & kValid) && (flj & kValid) && !((fli & kFrozen) && (flj & kFrozen));
+        if (act && ((moli == t.mol[jj]) || prefilter_within(bx, xi - t.x[jj], yi - t.y[jj], zi - t.z[jj])))
+            cand |= (1ull << jj);
+    }
+    while (cand) {
+        const int jj = __ffsll((long long)cand) - 1;
+        cand &= cand - 1ull;
+        const bool same = (moli == t.mol[jj]);
         double r2, ri2, dx, dy, dz;
         minimum_image_sq(bx, xi - t.x[jj], yi - t.y[jj], zi - t.z[jj], r2, ri2, dx, dy, dz);
-        const bool same = (moli == t.mol[jj]);
         const bool near = (ri2 <= rc2_hi);  // superset of every cutoff test below
         if (!near && !same) continue;
         const double rimg = near ? sqrt(ri2) : 2.0 * rc;

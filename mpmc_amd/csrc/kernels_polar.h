@@ -56,16 +56,25 @@ __global__ __launch_bounds__(64) void static_field_kernel(DevAtoms a, DevBox bx,
         smol[lane] = a.mol[j0 + lane];
         sfl[lane] = a.flags[j0 + lane];
         __syncthreads();
+        // Phase 1 (cheap, uniform): flag tests + fp32 distance screen for all 64 partners -> one bit each.
+        // Phase 2 (expensive, sparse): the exact fp64 path only for the set bits.  Done as two loops
+        // because a wave executes a divergent branch whenever ANY lane takes it: with ~3 % of the pairs
+        // inside the cutoff a fused loop still ran the exact path in ~86 % of its iterations.
+        unsigned long long cand = 0ull;
         for (int jj = 0; jj < kWave; ++jj) {
             const int j = j0 + jj;
             const int flj = sfl[jj];
-            const double qj = sq[jj];
             bool act = (j != i) && (fli & kValid) && (flj & kValid) && !((fli & kFrozen) && (flj & kFrozen)) &&
-                       (qj != 0.0);
+                       (sq[jj] != 0.0);
             // bare / Wolf fields skip same-molecule pairs (thole_field.c:50,96); the Ewald real term keeps
             // them and gives them the screening form instead (polar_ewald.c:52-60)
             if (MODE != kFieldEwald) act = act && (moli != smol[jj]);
-            if (!act) continue;
+            if (act && prefilter_within(bx, xi - sx[jj], yi - sy[jj], zi - sz[jj])) cand |= (1ull << jj);
+        }
+        while (cand) {
+            const int jj = __ffsll((long long)cand) - 1;
+            cand &= cand - 1ull;
+            const double qj = sq[jj];
             double r2, ri2, dx, dy, dz;
             minimum_image_sq(bx, xi - sx[jj], yi - sy[jj], zi - sz[jj], r2, ri2, dx, dy, dz);
             if (!(ri2 <= rc2_hi)) continue;
