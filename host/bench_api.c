@@ -24,6 +24,8 @@ int host_apply_config(system_t *system, const char *text) {
     }
     system->polar_iterative = 1;
     pbc(system);
+    if (system->ensemble == ENSEMBLE_UVT && !system->user_fugacities) system->fugacity = system->pressure;
+    if (system->ensemble == ENSEMBLE_UVT && !(system->fugacity > 0.0)) return 1;
     return 0;
 }
 
@@ -116,3 +118,22 @@ int host_set_option(system_t *system, const char *name, int value) {
     if (!system->hip_ctx) return -1;
     return mpmc_hip_set_option(system->hip_ctx, name, value);
 }
+
+int host_natoms(system_t *system) { return countNatoms(system); }
+/* full flat copy of the current configuration (N may have changed under uvt) */
+void host_get_system(system_t *system, double *pos, double *charge, double *alpha, double *eps, double *sig,
+                     double *mass, int *molecule, int *frozen) {
+    int i = 0, mi = 0;
+    for (molecule_t *m = system->molecules; m; m = m->next, mi++)
+        for (atom_t *a = m->atoms; a; a = a->next, i++) {
+            for (int p = 0; p < 3; p++) pos[3 * i + p] = a->pos[p];
+            charge[i] = a->charge;
+            alpha[i] = a->polarizability;
+            eps[i] = a->epsilon;
+            sig[i] = a->sigma;
+            mass[i] = a->mass;
+            molecule[i] = mi;
+            frozen[i] = a->frozen;
+        }
+}
+void host_set_ensemble(system_t *system, int ensemble) { system->ensemble = ensemble; }

@@ -150,8 +150,14 @@ static int delta_upload(system_t *system) {
 /* returns the total potential energy for the system and updates our observables */
 double energy(system_t *system) {
     system->natoms = countNatoms(system);
+    if (system->hip_ctx && system->natoms > system->hip_capacity) { /* uvt grew past the context */
+        mpmc_hip_destroy(system->hip_ctx);
+        system->hip_ctx = NULL;
+    }
     if (!system->hip_ctx) {
-        if (mpmc_hip_create(&system->hip_ctx, system->hip_device, system->natoms)) {
+        /* head-room for insertions: a context is sized once, like the reference's pair-list growth steps */
+        system->hip_capacity = system->natoms + (system->ensemble == ENSEMBLE_UVT ? system->natoms / 2 + 1024 : 0);
+        if (mpmc_hip_create(&system->hip_ctx, system->hip_device, system->hip_capacity)) {
             hip_fail("create");
             return NAN; /* mc.c treats a non-finite energy as a reject (mc.c:315-318) */
         }

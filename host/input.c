@@ -95,10 +95,12 @@ int do_command(system_t *system, char **token) {
     if (!strcasecmp(k, "ensemble")) {
         if (!strcasecmp(v, "nvt"))
             system->ensemble = ENSEMBLE_NVT;
+        else if (!strcasecmp(v, "uvt"))
+            system->ensemble = ENSEMBLE_UVT;
         else if (!strcasecmp(v, "total_energy"))
             system->ensemble = ENSEMBLE_TE;
         else {
-            error("INPUT: only `ensemble nvt` and `ensemble total_energy` are implemented by this host layer\n");
+            error("INPUT: only `ensemble nvt`, `uvt` and `total_energy` are implemented by this host layer\n");
             return 1;
         }
         return 0;
@@ -121,6 +123,21 @@ int do_command(system_t *system, char **token) {
     REAL("rot_factor", rot_factor);
     REAL("temperature", temperature);
     REAL("scale_charge", scale_charge);
+    REAL("insert_probability", insert_probability);
+    REAL("pressure", pressure);
+    if (!strcasecmp(k, "user_fugacities")) {
+        system->user_fugacities = 1;
+        return safe_atof(v, &system->fugacity);
+    }
+    if (!strcasecmp(k, "h2_fugacity") || !strcasecmp(k, "co2_fugacity") || !strcasecmp(k, "ch4_fugacity") ||
+        !strcasecmp(k, "n2_fugacity")) {
+        int on = 0;
+        if (on_off(v, &on)) return 1;
+        if (on && system->ensemble == ENSEMBLE_UVT)
+            error("INPUT: equation-of-state fugacities are not part of this host layer; the pressure (or "
+                  "user_fugacities) is used as the fugacity\n");
+        return 0;
+    }
     FLAG("rd_only", rd_only);
     FLAG("rd_lrc", rd_lrc);
     FLAG("feynman_hibbs", feynman_hibbs);
@@ -174,7 +191,7 @@ int do_command(system_t *system, char **token) {
     }
     /* keywords of the reference that do not touch the NVT energy path are accepted and ignored */
     {
-        static const char *ignored[] = {"insert_probability", "free_volume",   "h2_fugacity",    "pressure",
+        static const char *ignored[] = {"free_volume",
                                         "pqr_restart",        "traj_output",   "dipole_output",  "field_output",
                                         "pop_histogram",      "pop_histogram_output", "histogram_output", NULL};
         for (int i = 0; ignored[i]; i++)
@@ -318,8 +335,13 @@ static int check_system(system_t *system) {
         error("INPUT: `hip off` requested but this host layer has no CPU energy path\n");
         return -1;
     }
-    if (system->ensemble != ENSEMBLE_NVT && system->ensemble != ENSEMBLE_TE) {
-        error("INPUT: ensemble must be nvt or total_energy\n");
+    if (system->ensemble != ENSEMBLE_NVT && system->ensemble != ENSEMBLE_TE && system->ensemble != ENSEMBLE_UVT) {
+        error("INPUT: ensemble must be nvt, uvt or total_energy\n");
+        return -1;
+    }
+    if (system->ensemble == ENSEMBLE_UVT && !system->user_fugacities) system->fugacity = system->pressure;
+    if (system->ensemble == ENSEMBLE_UVT && !(system->fugacity > 0.0)) {
+        error("INPUT: uvt needs a pressure (or user_fugacities) > 0\n");
         return -1;
     }
     if (system->polarization) {
@@ -444,7 +466,7 @@ void free_system(system_t *system) {
     free(system->nodestats);
     free(system->avg_observables);
     if (system->checkpoint) {
-        free(system->checkpoint->backup_pos);
+        if (system->checkpoint->molecule_backup) free_molecule(system, system->checkpoint->molecule_backup);
         free(system->checkpoint->observables);
         free(system->checkpoint);
     }

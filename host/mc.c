@@ -121,62 +121,183 @@ void rotate(system_t *system, molecule_t *molecule, pbc_t *pbc, double scale) {
     }
 }
 
-/* choose the next molecule and back it up (reference checkpoint(), NVT/displace branch) */
+/* deep copy of a molecule and its atoms (reference copy_molecule(), src/mc/mc_moves.c:251-330) */
+molecule_t *copy_molecule(system_t *system, molecule_t *src) {
+    (void)system;
+    molecule_t *dst = calloc(1, sizeof(molecule_t));
+    memcpy(dst, src, sizeof(molecule_t));
+    dst->next = NULL;
+    dst->atoms = NULL;
+    atom_t *tail = NULL;
+    for (atom_t *a = src->atoms; a; a = a->next) {
+        atom_t *c = calloc(1, sizeof(atom_t));
+        memcpy(c, a, sizeof(atom_t));
+        c->next = NULL;
+        if (tail)
+            tail->next = c;
+        else
+            dst->atoms = c;
+        tail = c;
+    }
+    return dst;
+}
+
+void free_molecule(system_t *system, molecule_t *molecule) {
+    (void)system;
+    atom_t *a = molecule->atoms;
+    while (a) {
+        atom_t *n = a->next;
+        free(a);
+        a = n;
+    }
+    free(molecule);
+}
+
+/* (a) decides the next move, (b) backs up the state it will alter (reference checkpoint(),
+ * src/mc/checkpoint.c:4-186; the NVT and plain UVT branches) */
 void checkpoint(system_t *system) {
     checkpoint_t *cp = system->checkpoint;
     memcpy(cp->observables, system->observables, sizeof(observables_t));
-    cp->movetype = MOVETYPE_DISPLACE;
-    /* altered = floor(rand * N) over the non-frozen molecules in list order (checkpoint.c:121-123) */
+
+    int num_molecules_exchange = 0;
+    for (molecule_t *m = system->molecules; m; m = m->next)
+        if (!m->frozen) ++num_molecules_exchange;
+
+    if (system->ensemble == ENSEMBLE_UVT) {
+        if (get_rand(system) < system->insert_probability) {
+            if (get_rand(system) < 0.5)
+                cp->movetype = MOVETYPE_INSERT;
+            else
+                cp->movetype = MOVETYPE_REMOVE;
+        } else
+            cp->movetype = MOVETYPE_DISPLACE;
+    } else
+        cp->movetype = MOVETYPE_DISPLACE;
+
+    /* randomly pick a (moveable) molecule: floor(rand * N) over the exchangeable ones in list order */
+    --num_molecules_exchange;
     int altered = (int)floor(get_rand(system) * system->observables->N);
-    int k = 0, first = 0;
-    molecule_t *pick = NULL;
-    for (molecule_t *m = system->molecules; m; m = m->next) {
-        int cnt = 0;
-        for (atom_t *a = m->atoms; a; a = a->next) cnt++;
+    int k = 0;
+    molecule_t *pick = NULL, *prev = NULL, *head = NULL;
+    for (molecule_t *m = system->molecules; m; prev = m, m = m->next) {
         if (!m->frozen) {
             if (k == altered) {
                 pick = m;
-                cp->altered_first = first;
-                cp->altered_count = cnt;
+                head = prev;
                 break;
             }
             k++;
         }
-        first += cnt;
     }
     cp->molecule_altered = pick;
-    if (!pick) return;
-    cp->backup_pos = realloc(cp->backup_pos, 3 * (size_t)cp->altered_count * sizeof(double));
-    int i = 0;
-    for (atom_t *a = pick->atoms; a; a = a->next, i++)
-        for (int p = 0; p < 3; p++) cp->backup_pos[3 * i + p] = a->pos[p];
-    for (int p = 0; p < 3; p++) cp->backup_com[p] = pick->com[p];
+    /* never completely empty the list */
+    if (!num_molecules_exchange && cp->movetype == MOVETYPE_REMOVE) cp->movetype = MOVETYPE_DISPLACE;
+    cp->head = head;
+    cp->tail = pick ? pick->next : NULL;
+    if (cp->molecule_backup) {
+        free_molecule(system, cp->molecule_backup);
+        cp->molecule_backup = NULL;
+    }
+    if (pick) cp->molecule_backup = copy_molecule(system, pick);
 }
 
+/* apply what checkpoint() decided (reference make_move(), src/mc/mc_moves.c:567-741) */
 void make_move(system_t *system) {
-    molecule_t *m = system->checkpoint->molecule_altered;
-    if (!m) return;
-    translate(system, m, system->pbc, system->move_factor);
-    rotate(system, m, system->pbc, system->rot_factor);
+    checkpoint_t *cp = system->checkpoint;
+    if (!cp->molecule_altered) return;
+    switch (cp->movetype) {
+        case MOVETYPE_INSERT: {
+            /* insert a copy of the picked molecule at a random position and orientation */
+            double rand[3], com[3];
+            for (int p = 0; p < 3; p++) rand[p] = 0.5 - get_rand(system);
+            for (int p = 0; p < 3; p++) {
+                com[p] = 0;
+                for (int q = 0; q < 3; q++) com[p] += system->pbc->basis[q][p] * rand[q];
+            }
+            molecule_t *ins = cp->molecule_backup;
+            for (atom_t *a = ins->atoms; a; a = a->next)
+                for (int p = 0; p < 3; p++) a->pos[p] += com[p] - ins->com[p];
+            for (int p = 0; p < 3; p++) ins->com[p] = com[p];
+            rotate(system, ins, system->pbc, 1.0);
+            /* insert into the list, in front of the molecule it was copied from */
+            if (!cp->head)
+                system->molecules = ins;
+            else
+                cp->head->next = ins;
+            ins->next = cp->molecule_altered;
+            cp->molecule_altered = ins;
+            cp->tail = ins->next;
+            cp->molecule_backup = NULL;
+            break;
+        }
+        case MOVETYPE_REMOVE:
+            /* remove 'altered' from the list */
+            if (!cp->head)
+                system->molecules = system->molecules->next;
+            else
+                cp->head->next = cp->tail;
+            free_molecule(system, cp->molecule_altered);
+            cp->molecule_altered = NULL;
+            break;
+        default:
+            translate(system, cp->molecule_altered, system->pbc, system->move_factor);
+            rotate(system, cp->molecule_altered, system->pbc, system->rot_factor);
+    }
 }
 
 /* undo make_move() and pick the next move (reference restore(), mc_moves.c:744-807) */
 void restore(system_t *system) {
     checkpoint_t *cp = system->checkpoint;
     memcpy(system->observables, cp->observables, sizeof(observables_t));
-    if (cp->molecule_altered) {
-        int i = 0;
-        for (atom_t *a = cp->molecule_altered->atoms; a; a = a->next, i++)
-            for (int p = 0; p < 3; p++) a->pos[p] = cp->backup_pos[3 * i + p];
-        for (int p = 0; p < 3; p++) cp->molecule_altered->com[p] = cp->backup_com[p];
+    switch (cp->movetype) {
+        case MOVETYPE_INSERT:
+            /* take altered out of the list */
+            if (!cp->head)
+                system->molecules = system->molecules->next;
+            else
+                cp->head->next = cp->tail;
+            free_molecule(system, cp->molecule_altered);
+            cp->molecule_altered = NULL;
+            break;
+        case MOVETYPE_REMOVE:
+            /* put backup back into the list */
+            if (!cp->head)
+                system->molecules = cp->molecule_backup;
+            else
+                cp->head->next = cp->molecule_backup;
+            cp->molecule_backup->next = cp->tail;
+            cp->molecule_backup = NULL;
+            break;
+        default:
+            if (cp->molecule_altered) {
+                /* link the backup into the working list again */
+                if (!cp->head)
+                    system->molecules = cp->molecule_backup;
+                else
+                    cp->head->next = cp->molecule_backup;
+                cp->molecule_backup->next = cp->tail;
+                free_molecule(system, cp->molecule_altered);
+                cp->molecule_altered = NULL;
+                cp->molecule_backup = NULL;
+            }
     }
     checkpoint(system);
 }
 
-/* reference boltzmann_factor(), NVT branch (mc.c:106-114) */
+/* reference boltzmann_factor(), src/mc/mc.c:37-135: NVT, and UVT without cavity bias (one sorbate type) */
 void boltzmann_factor(system_t *system, double initial_energy, double final_energy) {
     const double delta_energy = final_energy - initial_energy;
-    system->nodestats->boltzmann_factor = exp(-delta_energy / system->temperature);
+    double bf = exp(-delta_energy / system->temperature);
+    if (system->ensemble == ENSEMBLE_UVT) {
+        const double fugacity = system->fugacity;
+        if (system->checkpoint->movetype == MOVETYPE_INSERT)
+            bf = system->pbc->volume * fugacity * ATM2REDUCED / (system->temperature * (double)(system->observables->N)) *
+                 exp(-delta_energy / system->temperature);
+        else if (system->checkpoint->movetype == MOVETYPE_REMOVE)
+            bf = system->temperature * ((double)(system->observables->N) + 1.0) /
+                 (system->pbc->volume * fugacity * ATM2REDUCED) * exp(-delta_energy / system->temperature);
+    }
+    system->nodestats->boltzmann_factor = bf;
 }
 
 /* reference write_observables(), src/io/output.c:988-1006 */

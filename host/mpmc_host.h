@@ -25,6 +25,7 @@ extern "C" {
 #define MAXLINE 512
 #define MAXVALUE 1.0e40
 #define E2REDUCED 408.7816 /* reference src/include/defines.h:45 */
+#define ATM2REDUCED 0.0073389366 /* convert from atm to K/A^3, defines.h:46 */
 
 enum { ENSEMBLE_UVT, ENSEMBLE_NVT, ENSEMBLE_SURF, ENSEMBLE_SURF_FIT, ENSEMBLE_NVE, ENSEMBLE_TE, ENSEMBLE_NPT,
        ENSEMBLE_REPLAY };
@@ -78,10 +79,8 @@ typedef struct _avg_observables {
 
 typedef struct _checkpoint {
     int movetype;
-    molecule_t *molecule_altered;
-    int altered_first, altered_count; /* flat atom range of molecule_altered */
-    double *backup_pos;               /* [altered_count][3] */
-    double backup_com[3];
+    molecule_t *molecule_altered, *molecule_backup; /* as in the reference: the backup is a deep copy */
+    molecule_t *head, *tail;                        /* neighbours of molecule_altered in the list */
     observables_t *observables;
 } checkpoint_t;
 
@@ -91,6 +90,8 @@ typedef struct _system {
     int hip;  /* keyword `hip on|off`; this layer has no CPU path, so it must stay on */
     int numsteps, corrtime, step;
     double move_factor, rot_factor, temperature, scale_charge;
+    double insert_probability, pressure, fugacity; /* uvt: fugacity = user_fugacities value, else pressure */
+    int user_fugacities;
     int preset_seeds_on;
     unsigned int preset_seeds;
     int rng_initialized;
@@ -113,7 +114,7 @@ typedef struct _system {
     double last_volume;
     /* device engine (opaque to callers) */
     mpmc_hip_ctx *hip_ctx;
-    int hip_device, hip_uploaded_natoms, hip_dirty_all;
+    int hip_device, hip_uploaded_natoms, hip_dirty_all, hip_capacity;
     mpmc_hip_timings hip_timings_sum; /* accumulated over energy() calls since mc() started */
     int hip_timing;
     FILE *fp_energy;
@@ -144,6 +145,8 @@ void make_move(system_t *system);
 void boltzmann_factor(system_t *system, double initial_energy, double final_energy);
 double get_rand(system_t *system);
 void seed_rng(unsigned int seed);
+molecule_t *copy_molecule(system_t *system, molecule_t *src);
+void free_molecule(system_t *system, molecule_t *molecule);
 void translate(system_t *system, molecule_t *molecule, pbc_t *pbc, double scale);
 void rotate(system_t *system, molecule_t *molecule, pbc_t *pbc, double scale);
 

@@ -38,6 +38,8 @@ def load():
     lib.host_get_observables.argtypes = [vp, vp]
     lib.host_get_positions.argtypes = [vp, vp]
     lib.host_get_dipoles.argtypes = [vp, vp, vp, vp]
+    lib.host_natoms.argtypes = [vp]
+    lib.host_get_system.argtypes = [vp] * 9
     lib.host_seed.argtypes = [vp, C.c_uint]
     lib.host_get_rand.argtypes = [vp]
     lib.host_get_rand.restype = C.c_double
@@ -76,7 +78,7 @@ def config_text(flags, extra=None):
 class HostSystem:
     """A system_t built from arrays, driven through the C host layer."""
 
-    def __init__(self, system, flags, device=0, seed=None, move_factor=0.01, rot_factor=0.01):
+    def __init__(self, system, flags, device=0, seed=None, move_factor=0.01, rot_factor=0.01, extra=None):
         self.lib = load()
         n = len(system["charge"])
         self.n = n
@@ -86,7 +88,7 @@ class HostSystem:
         arrs += [np.ascontiguousarray(system[k], dtype=np.int32) for k in ("molecule", "frozen")]
         arrs += [np.ascontiguousarray(system["basis"], dtype=np.float64).reshape(9)]
         self.ptr = C.c_void_p(self.lib.system_from_arrays(n, *[a.ctypes.data for a in arrs]))
-        extra = {"move_factor": move_factor, "rot_factor": rot_factor}
+        extra = dict({"move_factor": move_factor, "rot_factor": rot_factor}, **(extra or {}))
         if self.lib.host_apply_config(self.ptr, config_text(flags, extra).encode()) != 0:
             raise ValueError("host layer rejected the configuration")
         self.lib.host_set_device(self.ptr, device)
@@ -119,9 +121,24 @@ class HostSystem:
         return r
 
     def positions(self):
-        pos = np.zeros((self.n, 3))
+        pos = np.zeros((self.natoms(), 3))
         self.lib.host_get_positions(self.ptr, pos.ctypes.data)
         return pos
+
+    def natoms(self):
+        return int(self.lib.host_natoms(self.ptr))
+
+    def system(self, basis):
+        """Current configuration as a dict of arrays (N may differ from the initial one under uvt)."""
+        n = self.natoms()
+        f = {k: np.zeros(n) for k in ("charge", "alpha", "epsilon", "sigma", "mass")}
+        pos = np.zeros((n, 3))
+        mol = np.zeros(n, dtype=np.int32)
+        frz = np.zeros(n, dtype=np.int32)
+        self.lib.host_get_system(self.ptr, pos.ctypes.data, f["charge"].ctypes.data, f["alpha"].ctypes.data,
+                                 f["epsilon"].ctypes.data, f["sigma"].ctypes.data, f["mass"].ctypes.data,
+                                 mol.ctypes.data, frz.ctypes.data)
+        return dict(pos=pos, molecule=mol, frozen=frz, basis=np.asarray(basis, dtype=np.float64), **f)
 
     def dipoles(self):
         mu, es, ei = (np.zeros((self.n, 3)) for _ in range(3))

@@ -57,6 +57,29 @@ def test_same_seed_same_chain():
     assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1])
 
 
+def test_uvt_chain_inserts_removes_and_tracks_the_oracle():
+    """Grand-canonical chain (insert / remove / displace, reference mc.c:44-104, mc_moves.c:583-697):
+    N must fluctuate, and the energy the chain carries must equal the oracle's energy of whatever
+    configuration (and atom count) it ended in."""
+    s = synth.s_pol(160, spacing=4.5)
+    p = dict(temperature=77.0, polarization=1, polar_damp=2.1304, polar_max_iter=4)
+    h = host.HostSystem(s, p, seed=21, move_factor=0.05, rot_factor=0.05,
+                        extra={"ensemble": "uvt", "insert_probability": 0.6, "pressure": 300.0})
+    n0 = h.natoms()
+    seen = set()
+    for _ in range(12):
+        h.mc_steps(10)
+        seen.add(h.natoms())
+    o = h.observables()
+    assert len(seen) > 1, "N never changed"
+    assert all((n - n0) % 5 == 0 for n in seen)
+    final = h.system(s["basis"])
+    assert len(final["charge"]) == h.natoms() and o["N"] == h.natoms() // 5
+    want = oracle.energy(final, p)
+    assert abs(o["energy"] - want["energy"]) < 1e-9 * max(1.0, abs(want["energy"]))
+    h.close()
+
+
 def test_driver_executable_on_reference_style_input():
     """mpmc_hip <input> on the 10-atom box: the step-0 line of its energy_output must carry the
     reference's golden numbers (sample_configs_gpu/cuda_pol.small/noncuda_control/small.energy.dat:2)."""
