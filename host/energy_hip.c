@@ -78,6 +78,7 @@ static void fill_params(const system_t *s, mpmc_hip_params *p) {
     p->polar_ewald = s->polar_ewald;
     p->polar_ewald_alpha_set = 1;
     p->polar_ewald_alpha = s->polar_ewald_alpha;
+    p->wolf = s->wolf;
 }
 
 static int hip_fail(const char *what) {

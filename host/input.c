@@ -139,6 +139,7 @@ int do_command(system_t *system, char **token) {
         return 0;
     }
     FLAG("rd_only", rd_only);
+    FLAG("wolf", wolf);
     FLAG("rd_lrc", rd_lrc);
     FLAG("feynman_hibbs", feynman_hibbs);
     INT("feynman_hibbs_order", feynman_hibbs_order);

@@ -96,7 +96,7 @@ typedef struct _system {
     unsigned int preset_seeds;
     int rng_initialized;
     /* energy options (reference keywords) */
-    int rd_only, rd_lrc, feynman_hibbs, feynman_hibbs_order, wrapall;
+    int rd_only, rd_lrc, feynman_hibbs, feynman_hibbs_order, wrapall, wolf;
     int ewald_alpha_set, ewald_kmax, polar_ewald_alpha_set;
     double ewald_alpha, polar_ewald_alpha;
     int polarization, polar_iterative, polar_ewald, polar_zodid, polar_palmo, polar_gs, polar_gs_ranked, polar_sor,

@@ -65,6 +65,7 @@ typedef struct mpmc_hip_params {
     int polar_ewald;           /* polar_ewald: Ewald static field (polar_ewald.c:38-174)         */
     int polar_ewald_alpha_set; /* polar_ewald_alpha given explicitly                             */
     double polar_ewald_alpha;  /* else 3.5 / cutoff (pbc.c:75-76)                                */
+    int wolf;                  /* wolf: Wolf-summation electrostatics instead of Ewald (coulombic.c:269-308) */
 } mpmc_hip_params;
 
 /* What energy() leaves in system->observables / nodestats (structs.h:152-162),

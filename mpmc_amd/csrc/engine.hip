@@ -391,6 +391,8 @@ extern "C" int mpmc_hip_set_params(mpmc_hip_ctx *c, const mpmc_hip_params *p) {
         return fail("MPMC_HIP: feynman_hibbs_order must be 2 or 4");
     if (p->feynman_hibbs && !(p->temperature > 0.0)) return fail("MPMC_HIP: feynman_hibbs needs temperature > 0");
     if (p->ewald_kmax < 0 || p->ewald_kmax > 32) return fail("MPMC_HIP: ewald_kmax out of range");
+    if (p->wolf && p->feynman_hibbs && !p->rd_only)
+        return fail("MPMC_HIP: COULOMBIC: FH + es_wolf is not implemented");  // coulombic.c:294-298
     if (p->polarization) {
         if (!(p->polar_damp > 0.0)) return fail("MPMC_HIP: damping factor must be specified (polar_damp > 0)");
         if (p->polar_precision > 0.0 && p->polar_max_iter > 0)
@@ -689,7 +691,7 @@ extern "C" int mpmc_hip_energy(mpmc_hip_ctx *c, mpmc_hip_result *out) {
     const mpmc_hip_params &P = c->par;
     c->ewald_alpha = P.ewald_alpha_set ? P.ewald_alpha : 3.5 / c->cutoff;                    // pbc.c:73-74
     c->polar_ewald_alpha = P.polar_ewald_alpha_set ? P.polar_ewald_alpha : 3.5 / c->cutoff;  // pbc.c:75-76
-    if (!P.rd_only && (!c->kvec_valid || c->kvec_kmax != P.ewald_kmax)) {
+    if (!P.rd_only && !P.wolf && (!c->kvec_valid || c->kvec_kmax != P.ewald_kmax)) {
         if (build_kvectors(c)) return -1;
         c->kvec_kmax = P.ewald_kmax;
     }
@@ -734,6 +736,8 @@ extern "C" int mpmc_hip_energy(mpmc_hip_ctx *c, mpmc_hip_result *out) {
         pp.temperature = P.temperature;
         pp.rd_only = P.rd_only;
         pp.fh_order = P.feynman_hibbs ? P.feynman_hibbs_order : 0;
+        pp.wolf = P.wolf;
+        pp.erfaRoverR = std::erf(c->ewald_alpha * c->cutoff) / c->cutoff;
         const dim3 grid(ntile, ntile), block(64);
         if (pp.fh_order == 0)
             hipLaunchKernelGGL(pair_rd_es_kernel<0>, grid, block, 0, sb, a, bx, pp, c->d_pairpart);
@@ -745,8 +749,8 @@ extern "C" int mpmc_hip_energy(mpmc_hip_ctx *c, mpmc_hip_result *out) {
                            kPairChannels, c->d_res + R_RD_PAIR);
     }
 
-    // ---- reciprocal + self
-    if (!P.rd_only) {
+    // ---- reciprocal + self (absent under Wolf summation, coulombic.c:27-28)
+    if (!P.rd_only && !P.wolf) {
         ScopedTimer t(c, T_RECIP, sb);
         if (c->nk > 0) {
             hipLaunchKernelGGL(ewald_recip_kernel, dim3(c->nk), dim3(256), 0, sb, a, c->d_kvec, c->d_perk);
@@ -791,8 +795,9 @@ extern "C" int mpmc_hip_energy(mpmc_hip_ctx *c, mpmc_hip_result *out) {
     const double *r = c->h_res;
     const double rd = r[R_RD_PAIR] + r[R_LRC];
     const double real = r[R_ES_REAL] - r[R_ES_INTRA];
-    const double recip = P.rd_only ? 0.0 : r[R_RECIP] * (4.0 * kPI / c->volume);  // coulombic.c:92
-    const double self = P.rd_only ? 0.0 : r[R_SELF];
+    const bool ewald = !P.rd_only && !P.wolf;
+    const double recip = ewald ? r[R_RECIP] * (4.0 * kPI / c->volume) : 0.0;  // coulombic.c:92
+    const double self = ewald ? r[R_SELF] : 0.0;
     const double coul = P.rd_only ? 0.0 : real + recip + self;  // coulombic.c:36
     const double upol = do_polar ? r[R_UPOL] : 0.0;
     out->rd_energy = rd;

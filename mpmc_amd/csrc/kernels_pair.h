@@ -17,6 +17,8 @@ struct PairParams {
     double temperature;
     int rd_only;
     int fh_order;  // 0 = off, 2, 4
+    int wolf;      // Wolf electrostatics (coulombic.c:269-308) instead of the Ewald real term
+    double erfaRoverR;
 };
 
 constexpr int kPairChannels = 4;  // rd, es_real, es_intra, (spare)
@@ -117,7 +119,13 @@ __global__ __launch_bounds__(64) void pair_rd_es_kernel(DevAtoms a, DevBox bx, P
         }
 
         // ---- real-space Ewald: coulombic.c:149-194
-        if (!pp.rd_only) {
+        if (!pp.rd_only && pp.wolf) {
+            const bool es_excl = same || qi == 0.0 || qj == 0.0;
+            if (!es_excl && (rimg < rc)) {
+                const double iR = 1.0 / rc;
+                e_es += qi * qj * (1.0 / rimg - pp.erfaRoverR - iR * iR * (rc - rimg));
+            }
+        } else if (!pp.rd_only) {
             const bool es_excl = same || qi == 0.0 || qj == 0.0;
             if (!es_excl && !(rimg > rc)) {
                 const double erfc_term = erfc(alpha * rimg);

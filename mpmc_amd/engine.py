@@ -49,6 +49,7 @@ class Params(C.Structure):
         ("polar_ewald", C.c_int),
         ("polar_ewald_alpha_set", C.c_int),
         ("polar_ewald_alpha", C.c_double),
+        ("wolf", C.c_int),
     ]
 
 

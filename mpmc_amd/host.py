@@ -58,7 +58,7 @@ def load():
 def config_text(flags, extra=None):
     """flags in C-ABI / oracle naming -> the reference's keyword lines."""
     onoff = {"rd_only", "rd_lrc", "feynman_hibbs", "polarization", "polar_gs", "polar_gs_ranked", "polar_sor",
-             "polar_esor", "polar_palmo", "polar_rrms", "polar_zodid", "polar_wolf", "polar_ewald"}
+             "polar_esor", "polar_palmo", "polar_rrms", "polar_zodid", "polar_wolf", "polar_ewald", "wolf"}
     lines = []
     for k, v in flags.items():
         if k in onoff:

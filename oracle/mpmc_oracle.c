@@ -309,6 +309,25 @@ static double coulombic_real(const octx *c) {
     return potential;
 }
 
+/* energy/coulombic.c:269-308 */
+static double coulombic_wolf(const octx *c) {
+    const orc_system *s = c->s;
+    int i, j, n = c->n;
+    double pot = 0, alpha = c->ewald_alpha, R = c->cutoff, iR = 1.0 / R, erfaRoverR = erf(alpha * R) / R;
+    opair pr;
+    for (i = 0; i < n - 1; i++)
+        for (j = i + 1; j < n; j++) {
+            double es_real_energy = 0, r, ir;
+            make_pair(c, i, j, &pr);
+            r = pr.rimg;
+            ir = 1.0 / r;
+            if ((!pr.frozen) && (!pr.es_excluded) && (r < R))
+                es_real_energy = s->charge[i] * s->charge[j] * (ir - erfaRoverR - iR * iR * (R - r));
+            pot += es_real_energy;
+        }
+    return pot;
+}
+
 int orc_kvector_count(int kmax) {
     int l0, l1, l2, cnt = 0;
     for (l0 = 0; l0 <= kmax; l0++)
@@ -818,10 +837,17 @@ int orc_energy(const orc_system *sys, const orc_params *par, orc_result *res, or
     res->rd_energy = rd_energy;
     if (!(par->rd_only)) {
         double real, reciprocal, self;
-        real = coulombic_real(&c);
-        reciprocal = coulombic_reciprocal(&c);
-        self = coulombic_self(&c);
-        coulombic_energy = real + reciprocal + self;
+        if (par->wolf) { /* coulombic.c:27-28 */
+            real = coulombic_wolf(&c);
+            reciprocal = 0;
+            self = 0;
+            coulombic_energy = real;
+        } else {
+            real = coulombic_real(&c);
+            reciprocal = coulombic_reciprocal(&c);
+            self = coulombic_self(&c);
+            coulombic_energy = real + reciprocal + self;
+        }
         res->es_real = real;
         res->es_recip = reciprocal;
         res->es_self = self;

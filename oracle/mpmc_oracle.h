@@ -53,6 +53,7 @@ typedef struct orc_params {
     int polar_ewald;             /* "polar_ewald" (static field via Ewald)      */
     int polar_ewald_alpha_set;   /* "polar_ewald_alpha" given                   */
     double polar_ewald_alpha;
+    int wolf;                    /* "wolf": Wolf electrostatics (coulombic.c:269-308)   */
 } orc_params;
 
 /* one configuration, atoms in the reference's list order (molecule by molecule) */

@@ -41,6 +41,7 @@ class OrcParams(C.Structure):
         ("polar_ewald", C.c_int),
         ("polar_ewald_alpha_set", C.c_int),
         ("polar_ewald_alpha", C.c_double),
+        ("wolf", C.c_int),
     ]
 
 

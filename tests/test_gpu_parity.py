@@ -115,6 +115,20 @@ def test_ewald_options():
     check_energies(run_engine(s, p), oracle.energy(s, p))
 
 
+def test_wolf_electrostatics():
+    """coulombic_wolf (coulombic.c:269-308): no reciprocal / self terms; FH + wolf is refused as in the reference."""
+    s = synth.s_es(1024)
+    p = dict(temperature=100.0, wolf=1)
+    got = run_engine(s, p)
+    want = oracle.energy(s, p)
+    check_energies(got, want)
+    assert got["es_recip"] == 0.0 and got["es_self"] == 0.0 and got["es_real"] != 0.0
+    eng = engine.Engine(16)
+    with pytest.raises(engine.EngineError):
+        eng.set_params(temperature=100.0, wolf=1, feynman_hibbs=1, feynman_hibbs_order=2)
+    eng.close()
+
+
 def test_triclinic_box():
     s = synth.s_es(432)
     L = s["basis"][0, 0]
