@@ -125,26 +125,35 @@ static int full_upload(system_t *system) {
     return 0;
 }
 
-/* send only what changed since the previous call */
+/* send only what changed since the previous call: one short range per moved molecule (after a rejected
+ * move two molecules differ from the device copy -- the restored one and the newly displaced one -- and
+ * they can be far apart in the list, so changed atoms are grouped into separate ranges) */
 static int delta_upload(system_t *system) {
     shadow_t *sh = &g_shadow;
     const int n = system->natoms;
-    int i = 0, lo = n, hi = -1;
+    int i = 0;
     for (molecule_t *m = system->molecules; m; m = m->next)
         for (atom_t *a = m->atoms; a; a = a->next, i++) {
             sh->tx[i] = a->pos[0]; sh->ty[i] = a->pos[1]; sh->tz[i] = a->pos[2];
-            if (sh->tx[i] != sh->x[i] || sh->ty[i] != sh->y[i] || sh->tz[i] != sh->z[i]) {
-                if (i < lo) lo = i;
-                if (i > hi) hi = i;
-            }
         }
-    if (hi < 0) return 0;
-    /* a displacement touches one molecule => one short contiguous range */
-    if (mpmc_hip_update_atoms(system->hip_ctx, lo, hi - lo + 1, sh->tx + lo, sh->ty + lo, sh->tz + lo))
-        return hip_fail("update_atoms");
-    memcpy(sh->x + lo, sh->tx + lo, (hi - lo + 1) * sizeof(double));
-    memcpy(sh->y + lo, sh->ty + lo, (hi - lo + 1) * sizeof(double));
-    memcpy(sh->z + lo, sh->tz + lo, (hi - lo + 1) * sizeof(double));
+    int lo = -1, hi = -1; /* current open range */
+    for (i = 0; i <= n; i++) {
+        const int changed = (i < n) && (sh->tx[i] != sh->x[i] || sh->ty[i] != sh->y[i] || sh->tz[i] != sh->z[i]);
+        if (changed) {
+            if (lo < 0) lo = i;
+            hi = i;
+        }
+        /* close the range once 8 unchanged atoms (or the end) follow it */
+        if (lo >= 0 && (i == n || (!changed && i - hi >= 8))) {
+            const int cnt = hi - lo + 1;
+            if (mpmc_hip_update_atoms(system->hip_ctx, lo, cnt, sh->tx + lo, sh->ty + lo, sh->tz + lo))
+                return hip_fail("update_atoms");
+            memcpy(sh->x + lo, sh->tx + lo, cnt * sizeof(double));
+            memcpy(sh->y + lo, sh->ty + lo, cnt * sizeof(double));
+            memcpy(sh->z + lo, sh->tz + lo, cnt * sizeof(double));
+            lo = hi = -1;
+        }
+    }
     return 0;
 }
 
