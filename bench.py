@@ -166,7 +166,8 @@ def main():
         n_pol = int(np.count_nonzero(np.asarray(system["alpha"]) != 0.0))
         m3 = 3.0 * n_pol
         sweep_bytes = m3 * (m3 + 1) / 2 * 8 + 3 * m3 * 8
-        if args.full_sweep:
+        sym_off = ((n_pol + 127) // 128 * 128) < 2048  # the engine's size threshold for the symmetric kernel
+        if args.full_sweep or sym_off:
             sweep_bytes = m3 * m3 * 8 + 5 * m3 * 8
         achieved = sweep_bytes / (sweep_avg_ms * 1e-3) / 1e9 if sweep_avg_ms > 0 else 0.0
         traffic = None
@@ -193,7 +194,7 @@ def main():
                     "random MC moves",
             "config": {"workload": label, "n_atoms": n, "n_polarizable": n_pol, "walkers": world, "corrtime": args.corrtime,
                        "parallelism": "%d independent walkers, 1 per GPU" % world},
-            "roofline": {"kernel": ("sweep_kernel<Jacobi>" if args.full_sweep else "symv_kernel") +
+            "roofline": {"kernel": ("sweep_kernel<Jacobi>" if (args.full_sweep or sym_off) else "symv_kernel") +
                                    " (Thole field / dipole sweep)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
