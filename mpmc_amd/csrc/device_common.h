@@ -150,8 +150,13 @@ __device__ __forceinline__ void minimum_image_sq(const DevBox &bx, double dx, do
 // rounding of coordinates below ~100 A moves a distance by < 1e-4 A, and if fp32 picks the other image
 // of a tie both images are equidistant to that accuracy, so no pair the exact test accepts is lost.
 // Pairs that pass are decided by the exact fp64 path as before, so results are unchanged.
+__device__ __forceinline__ bool prefilter_within_f(const DevBox &bx, float dx, float dy, float dz);
 __device__ __forceinline__ bool prefilter_within(const DevBox &bx, double dxd, double dyd, double dzd) {
-    const float dx = (float)dxd, dy = (float)dyd, dz = (float)dzd;
+    return prefilter_within_f(bx, (float)dxd, (float)dyd, (float)dzd);
+}
+// same screen on single-precision displacements (coordinates rounded to fp32 when a tile is staged:
+// |x| < 64 A => 4e-6 A per coordinate, far inside the 0.01 A margin)
+__device__ __forceinline__ bool prefilter_within_f(const DevBox &bx, float dx, float dy, float dz) {
     float i0 = bx.frb[0][0] * dx + bx.frb[1][0] * dy + bx.frb[2][0] * dz;
     float i1 = bx.frb[0][1] * dx + bx.frb[1][1] * dy + bx.frb[2][1] * dz;
     float i2 = bx.frb[0][2] * dx + bx.frb[1][2] * dy + bx.frb[2][2] * dz;

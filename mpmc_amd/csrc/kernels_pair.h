@@ -25,6 +25,7 @@ constexpr int kPairChannels = 4;  // rd, es_real, es_intra, (spare)
 
 struct JTile {
     double x[kWave], y[kWave], z[kWave], q[kWave], eps[kWave], sig[kWave], mm[kWave];
+    float fx[kWave], fy[kWave], fz[kWave];  // fp32 copies for the screening pass
     int mol[kWave], flags[kWave];
 };
 
@@ -33,6 +34,9 @@ __device__ __forceinline__ void load_jtile(JTile &t, const DevAtoms &a, int j0, 
     t.x[lane] = a.x[j];
     t.y[lane] = a.y[j];
     t.z[lane] = a.z[j];
+    t.fx[lane] = (float)t.x[lane];
+    t.fy[lane] = (float)t.y[lane];
+    t.fz[lane] = (float)t.z[lane];
     t.q[lane] = a.q[j];
     t.eps[lane] = a.eps[j];
     t.sig[lane] = a.sig[j];
@@ -58,6 +62,7 @@ __global__ __launch_bounds__(64) void pair_rd_es_kernel(DevAtoms a, DevBox bx, P
 
     const int i = I * kWave + lane;
     const double xi = a.x[i], yi = a.y[i], zi = a.z[i];
+    const float xif = (float)xi, yif = (float)yi, zif = (float)zi;
     const double qi = a.q[i], epsi = a.eps[i], sigi = a.sig[i], mmi = a.molmass[i];
     const int moli = a.mol[i], fli = a.flags[i];
     const double rc = bx.cutoff;
@@ -74,7 +79,7 @@ __global__ __launch_bounds__(64) void pair_rd_es_kernel(DevAtoms a, DevBox bx, P
         const int flj = t.flags[jj];
         // pair (i<j), both real atoms, not frozen-frozen (lj.c:193, coulombic.c:165)
         const bool act = (j > i) && (fli & kValid) && (flj & kValid) && !((fli & kFrozen) && (flj & kFrozen));
-        if (act && ((moli == t.mol[jj]) || prefilter_within(bx, xi - t.x[jj], yi - t.y[jj], zi - t.z[jj])))
+        if (act && ((moli == t.mol[jj]) || prefilter_within_f(bx, xif - t.fx[jj], yif - t.fy[jj], zif - t.fz[jj])))
             cand |= (1ull << jj);
     }
     while (cand) {

@@ -37,9 +37,11 @@ __global__ __launch_bounds__(64) void static_field_kernel(DevAtoms a, DevBox bx,
     const int i = blockIdx.y * kWave + lane;
     const int jbeg = blockIdx.x * fp.chunk;
     __shared__ double sx[kWave], sy[kWave], sz[kWave], sq[kWave];
+    __shared__ float fx[kWave], fy[kWave], fz[kWave];  // fp32 copies for the screening pass
     __shared__ int smol[kWave], sfl[kWave];
 
     const double xi = a.x[i], yi = a.y[i], zi = a.z[i];
+    const float xif = (float)xi, yif = (float)yi, zif = (float)zi;
     const double qi = a.q[i];
     const int moli = a.mol[i], fli = a.flags[i];
     const double rc = bx.cutoff;
@@ -52,9 +54,12 @@ __global__ __launch_bounds__(64) void static_field_kernel(DevAtoms a, DevBox bx,
         sx[lane] = a.x[j0 + lane];
         sy[lane] = a.y[j0 + lane];
         sz[lane] = a.z[j0 + lane];
+        fx[lane] = (float)sx[lane];
+        fy[lane] = (float)sy[lane];
+        fz[lane] = (float)sz[lane];
         sq[lane] = a.q[j0 + lane];
         smol[lane] = a.mol[j0 + lane];
-        sfl[lane] = a.flags[j0 + lane];
+        sfl[lane] = (sq[lane] != 0.0) ? a.flags[j0 + lane] : 0;  // uncharged partners never contribute a field
         __syncthreads();
         // Phase 1 (cheap, uniform): flag tests + fp32 distance screen for all 64 partners -> one bit each.
         // Phase 2 (expensive, sparse): the exact fp64 path only for the set bits.  Done as two loops
@@ -64,12 +69,11 @@ __global__ __launch_bounds__(64) void static_field_kernel(DevAtoms a, DevBox bx,
         for (int jj = 0; jj < kWave; ++jj) {
             const int j = j0 + jj;
             const int flj = sfl[jj];
-            bool act = (j != i) && (fli & kValid) && (flj & kValid) && !((fli & kFrozen) && (flj & kFrozen)) &&
-                       (sq[jj] != 0.0);
+            bool act = (j != i) && (fli & kValid) && (flj & kValid) && !((fli & kFrozen) && (flj & kFrozen));
             // bare / Wolf fields skip same-molecule pairs (thole_field.c:50,96); the Ewald real term keeps
             // them and gives them the screening form instead (polar_ewald.c:52-60)
             if (MODE != kFieldEwald) act = act && (moli != smol[jj]);
-            if (act && prefilter_within(bx, xi - sx[jj], yi - sy[jj], zi - sz[jj])) cand |= (1ull << jj);
+            if (act && prefilter_within_f(bx, xif - fx[jj], yif - fy[jj], zif - fz[jj])) cand |= (1ull << jj);
         }
         while (cand) {
             const int jj = __ffsll((long long)cand) - 1;

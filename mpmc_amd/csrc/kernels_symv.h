@@ -35,10 +35,13 @@ constexpr int kSymRowAtoms = 32;     // rows per unit = 96
 template <int POLICY>
 __global__ __launch_bounds__(64) void symv_kernel(const double *__restrict__ A, int lda, int nvpad,
                                                    const double *__restrict__ x, double *__restrict__ Srow,
-                                                   double *__restrict__ Zcol, int reverse) {
+                                                   double *__restrict__ Zcol, int reverse, int nv) {
     const int lane = threadIdx.x;
     const int ch = reverse ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
     const int rb = reverse ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;
+    // row-blocks made of padding only hold zero rows; nobody reads their partial sums (the finish kernel
+    // discards rows >= nv and only sums column partials of row-blocks above an atom's own chunk)
+    if (rb * kSymRowAtoms >= nv) return;
     const int dch = rb / (kSymChunkAtoms / kSymRowAtoms);
     if (ch < dch) return;
     const bool diag = (ch == dch);
