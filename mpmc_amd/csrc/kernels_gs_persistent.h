@@ -3,14 +3,15 @@
 //
 // Workgroup 0 is the SPINE: it walks the blocks in order and runs the serial forward substitution.
 // Workgroups 1..G-1 are OWNERS of target blocks (t mod (G-1)): an owner accumulates
-//   ypart_t = y_upper_t - sum_{s <= t-2} T(t,s) mu_new_s
-// as the spine publishes mu_new_s, and hands ypart_t to the spine.  The spine adds the one
-// contribution nobody else can have ready in time, s = t-1, itself.
+//   ypart_t = y_upper_t - sum_{s < t} T(t,s) mu_new_s
+// as the spine publishes mu_new_s (its tile loads are issued before each wait, so only the last
+// source, s = t-1, costs a hand-off on the critical path), and hands ypart_t to the spine.
 //
-// The critical path per block is the 64-step in-wave chain plus two workgroup barriers; every HBM
-// access of the spine is taken off it: while wave 0 runs the chain of block t, waves 1-7 load the
-// neighbour tile T(t+1,t) and the diagonal tile of block t+1 into REGISTERS (neither
-// depends on the dipoles); after the chain they only multiply / copy to LDS.
+// A single CU pulls only ~24 GB/s from HBM, so the spine touches as few bytes as possible: while
+// wave 0 runs the chain of block t, waves 1-7 load the strictly-upper diagonal tile of block t+1
+// (97 KB, independent of the dipoles) into REGISTERS and copy it to LDS after the chain.  An earlier
+// variant that also kept the neighbour tile T(t+1,t) (196 KB) in the spine spent ~12 us per block
+// just fetching; handing that tile to the owner costs one flag round trip (~4 us) instead.
 //
 // Cross-workgroup hand-offs follow the gfx950 recipe (cdna_hip_programming.md, Guideline 16):
 // payload written with agent-scope relaxed atomic stores (write-through, sc1), every storing wave
@@ -38,7 +39,7 @@ struct GsPersist {
 
 constexpr int kGsPairs = kGsBlock * (kGsBlock - 1) / 2;       // 2016
 constexpr int kGsTileDoubles = kGsPairs * 6;                  // 12096
-constexpr int kGsPersistLds = (kGsTileDoubles + 3 * kGsBlock + 8 * 3 * kGsBlock + 8) * 8;
+constexpr int kGsPersistLds = (kGsTileDoubles + 3 * kGsBlock + 8 * 3 * kGsBlock + 8) * 8;  // spine: tile + smu; owner: smu + part[8]
 constexpr unsigned kGsSpinLimit = 1u << 24;
 
 __device__ __forceinline__ int gs_row_offset(int j) { return j * (kGsBlock - 1) - j * (j - 1) / 2; }
@@ -82,7 +83,7 @@ __device__ void gs_owner(const GsPersist &p, int first, int stride, double *lds)
     for (int t = first; t < p.nb; t += stride) {
         const int k = t * kGsBlock + lane;  // this lane's target atom
         double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-        for (int s = 0; s + 2 <= t; ++s) {
+        for (int s = 0; s + 1 <= t; ++s) {
             // tile loads first: they do not depend on the dipoles and hide behind the wait
             double tt[8][6];
             const double *base = p.A + (size_t)(3 * (s * kGsBlock + 8 * w)) * p.lda + 3 * (size_t)k;
@@ -136,9 +137,7 @@ __device__ void gs_spine(const GsPersist &p, double *lds) {
     const size_t lda = (size_t)p.lda;
 
     // what this thread prefetches for the NEXT block while wave 0 runs the chain
-    // waves 1-7 (448 helper threads): neighbour tensors T(j, l = lane of block t+1) for the sources
-    // j = g, g+7, g+14, ... (g = w-1), and 5 (4 for some) pairs of the next diagonal tile
-    double nreg[10][6];
+    // waves 1-7 (448 helper threads): 5 (4 for some) pairs each of the next diagonal tile
     double dreg[5][6];
     // the (j, l > j) pairs of the diagonal tile this helper thread stages: idx = th + 448 q, row-major over j
     int dj[5], dl[5];
@@ -156,14 +155,6 @@ __device__ void gs_spine(const GsPersist &p, double *lds) {
         }
     }
     auto prefetch = [&](int tn) {  // tn = block whose tiles are fetched
-        if (w >= 1 && tn >= 1) {
-            const double *base = p.A + (size_t)(3 * (tn - 1) * kGsBlock) * lda + 3 * (size_t)(tn * kGsBlock + lane);
-#pragma unroll
-            for (int jj = 0; jj < 10; ++jj) {
-                const int j = (w - 1) + 7 * jj;
-                if (j < kGsBlock) load_tensor6(base + (size_t)(3 * j) * lda, lda, nreg[jj]);
-            }
-        }
         if (w >= 1) {
             const int th = (w - 1) * 64 + lane;  // 0..447
 #pragma unroll
@@ -180,22 +171,6 @@ __device__ void gs_spine(const GsPersist &p, double *lds) {
     for (int t = 0; t < p.nb; ++t) {
         // ---- [A] neighbour contribution of block t-1 (registers x smu), [B] diagonal tile -> LDS
         if (w >= 1) {
-            double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-            if (t >= 1) {
-#pragma unroll
-                for (int jj = 0; jj < 10; ++jj) {
-                    const int j = (w - 1) + 7 * jj;
-                    if (j < kGsBlock) {
-                        const double mx = smu[3 * j], my = smu[3 * j + 1], mz = smu[3 * j + 2];
-                        a0 += nreg[jj][0] * mx + nreg[jj][1] * my + nreg[jj][2] * mz;
-                        a1 += nreg[jj][1] * mx + nreg[jj][3] * my + nreg[jj][4] * mz;
-                        a2 += nreg[jj][2] * mx + nreg[jj][4] * my + nreg[jj][5] * mz;
-                    }
-                }
-            }
-            part[((w - 1) * 3 + 0) * kGsBlock + lane] = a0;
-            part[((w - 1) * 3 + 1) * kGsBlock + lane] = a1;
-            part[((w - 1) * 3 + 2) * kGsBlock + lane] = a2;
             const int th = (w - 1) * 64 + lane;
 #pragma unroll
             for (int q = 0; q < 5; ++q) {
@@ -224,12 +199,6 @@ __device__ void gs_spine(const GsPersist &p, double *lds) {
                 y0 = ld_agent(p.ypart + (size_t)t * 3 * kGsBlock + 3 * lane);
                 y1 = ld_agent(p.ypart + (size_t)t * 3 * kGsBlock + 3 * lane + 1);
                 y2 = ld_agent(p.ypart + (size_t)t * 3 * kGsBlock + 3 * lane + 2);
-#pragma unroll
-                for (int g = 0; g < 7; ++g) {
-                    y0 -= part[(g * 3 + 0) * kGsBlock + lane];
-                    y1 -= part[(g * 3 + 1) * kGsBlock + lane];
-                    y2 -= part[(g * 3 + 2) * kGsBlock + lane];
-                }
                 const double al = p.alpha[k];
                 const double ae0 = al * p.es[3 * k], ae1 = al * p.es[3 * k + 1], ae2 = al * p.es[3 * k + 2];
                 // The chain is issue-bound (one wave, ~30 instructions per step), so it is fully unrolled:
