@@ -50,25 +50,35 @@ def load_workload(name):
 
 
 def cpu_baseline(system, flags, budget_s=20.0):
-    """The CPU oracle (a port of the reference path) timed on this host, 1 core, bounded sample."""
+    """The CPU oracle (a port of the reference path, including its per-pair caching between steps)
+    timed on this host, 1 core, bounded sample of the same workload: single-molecule moves + energy()."""
     from oracle import oracle
 
+    n = len(system["charge"])
+    mol = np.asarray(system["molecule"])
+    frozen = np.asarray(system["frozen"])
+    starts = np.flatnonzero(np.r_[True, mol[1:] != mol[:-1]])
+    ends = np.r_[starts[1:], n]
+    movable = [(int(a), int(b)) for a, b in zip(starts, ends) if not frozen[a]]
+    rng = np.random.default_rng(7)
+    s = dict(system)
+    s["pos"] = np.array(system["pos"], dtype=np.float64)
+    cache = oracle.Cache(n)
+    oracle.energy(s, flags, cache=cache)  # first call computes every pair (untimed, like the GPU warm-up)
     t0 = time.perf_counter()
     nstep = 0
-    pos = np.array(system["pos"])
-    s = dict(system)
-    rng = np.random.default_rng(7)
     while True:
-        s["pos"] = pos + 0.0
-        s["pos"][-1] += 0.01 * rng.random(3)
-        oracle.energy(s, flags)
+        a, b = movable[rng.integers(len(movable))]
+        s["pos"][a:b] += 0.05 * (rng.random(3) - 0.5)
+        oracle.energy(s, flags, cache=cache)
         nstep += 1
         el = time.perf_counter() - t0
-        if el > budget_s or nstep >= 50:
+        if el > budget_s or nstep >= 200:
             break
+    cache.close()
     return dict(value=nstep / el, unit="MC steps/s", cores=1, kind="port",
-                sample="%d full energy() evaluations of the same workload by oracle/ (C restatement of the "
-                       "reference CPU path, gcc -O3, 1 thread), %.1f s" % (nstep, el))
+                sample="%d single-molecule moves + energy() of the same workload by oracle/ (C restatement of the "
+                       "reference CPU path with its per-pair caching, gcc -O3, 1 thread), %.1f s" % (nstep, el))
 
 
 def main():

@@ -31,9 +31,26 @@
 /* polarization/thole_field.c:10 */
 #define ORC_OneOverSqrtPi 0.56418958354
 
+/* Per-pair state that the reference keeps in its linked pair list between energy() calls
+ * (pair_t: d_prev, r, rimg, dimg, recalculate_energy, rd_energy, lrc, es_real_energy,
+ * es_self_intra_energy; include/structs.h:21-37).  With it, an energy() after a single-molecule move
+ * redoes the pair arithmetic only for pairs whose displacement changed (pairs.c:238-249), exactly
+ * like the reference -- which is what makes this port a fair CPU baseline for MC stepping. */
+struct orc_cache {
+    int n, primed;
+    size_t np;
+    double *d_prev, *r, *rimg, *dimg, *rd, *lrc, *es_real, *es_intra;
+    unsigned char *recalc;
+};
+
+static size_t pair_index(int n, int i, int j) { /* i < j */
+    return (size_t)i * (size_t)n - (size_t)i * ((size_t)i + 1) / 2 + (size_t)(j - i - 1);
+}
+
 typedef struct {
     const orc_system *s;
     const orc_params *p;
+    struct orc_cache *cache;
     int n;
     int *midx;        /* molecule index per atom (contiguous runs of equal id) */
     double *molmass;  /* per atom: mass of its molecule (update_com, pairs.c:364-385) */
@@ -158,12 +175,57 @@ static void pair_exclusions(const octx *c, int i, int j, opair *pr) {
 /* one pair as pairs() leaves it (pairs.c:312-328): frozen pairs get no geometry unless polarization is on */
 static void make_pair(const octx *c, int i, int j, opair *pr) {
     pair_exclusions(c, i, j, pr);
+    if (c->cache) { /* geometry as stored by pairs_update() */
+        const size_t k = pair_index(c->n, i, j);
+        pr->r = c->cache->r[k];
+        pr->rimg = c->cache->rimg[k];
+        pr->dimg[0] = c->cache->dimg[3 * k];
+        pr->dimg[1] = c->cache->dimg[3 * k + 1];
+        pr->dimg[2] = c->cache->dimg[3 * k + 2];
+        return;
+    }
     if (!pr->frozen || c->p->polarization)
         orc_minimum_image(c->s->basis, c->recip, c->s->pos + 3 * i, c->s->pos + 3 * j, &pr->r, &pr->rimg, pr->dimg);
     else {
         pr->r = pr->rimg = 0;
         pr->dimg[0] = pr->dimg[1] = pr->dimg[2] = 0;
     }
+}
+
+/* pairs(), energy/pairs.c:293-330 with minimum_image() :230-290: geometry is redone only for pairs whose
+ * raw displacement changed since the previous call; those pairs get recalculate_energy = 1 */
+static void pairs_update(const octx *c) {
+    struct orc_cache *h = c->cache;
+    const orc_system *s = c->s;
+    int i, j, p, n = c->n;
+    opair pr;
+    for (i = 0; i < n - 1; i++)
+        for (j = i + 1; j < n; j++) {
+            const size_t k = pair_index(n, i, j);
+            double d[3];
+            int changed = !h->primed; /* flag_all_pairs() on the first call, energy.c:96-97 */
+            const int frozen = s->frozen[i] && s->frozen[j];
+            if (frozen && !c->p->polarization) {
+                h->recalc[k] = (unsigned char)changed;
+                continue;
+            }
+            for (p = 0; p < 3; p++) {
+                d[p] = s->pos[3 * i + p] - s->pos[3 * j + p];
+                if (d[p] != h->d_prev[3 * k + p]) {
+                    changed = 1;
+                    h->d_prev[3 * k + p] = d[p];
+                }
+            }
+            h->recalc[k] = (unsigned char)changed;
+            if (changed) {
+                orc_minimum_image(s->basis, c->recip, s->pos + 3 * i, s->pos + 3 * j, &pr.r, &pr.rimg, pr.dimg);
+                h->r[k] = pr.r;
+                h->rimg[k] = pr.rimg;
+                h->dimg[3 * k] = pr.dimg[0];
+                h->dimg[3 * k + 1] = pr.dimg[1];
+                h->dimg[3 * k + 2] = pr.dimg[2];
+            }
+        }
 }
 
 /* energy/lj.c:11-54 */
@@ -225,6 +287,11 @@ static double lj(const octx *c) {
     for (i = 0; i < n - 1; i++)
         for (j = i + 1; j < n; j++) {
             double rd_energy = 0, lrc = 0;
+            if (c->cache && !c->cache->recalc[pair_index(n, i, j)]) { /* lj.c:182: stored values */
+                const size_t k = pair_index(n, i, j);
+                potential += c->cache->rd[k] + c->cache->lrc[k];
+                continue;
+            }
             make_pair(c, i, j, &pr);
             if (c->p->rd_lrc) lrc = lj_lrc_corr(c, &pr, cutoff);
             if ((pr.rimg - ORC_SMALL_dR < cutoff) && (!pr.rd_excluded) && !pr.frozen) {
@@ -242,6 +309,10 @@ static double lj(const octx *c) {
                 rd_energy += potential_classical;
                 if (c->p->feynman_hibbs)
                     rd_energy += lj_fh_corr(c, i, j, &pr, c->p->feynman_hibbs_order, term12, term6);
+            }
+            if (c->cache) {
+                c->cache->rd[pair_index(n, i, j)] = rd_energy;
+                c->cache->lrc[pair_index(n, i, j)] = lrc;
             }
             potential += rd_energy + lrc;
         }
@@ -291,6 +362,14 @@ static double coulombic_real(const octx *c) {
     for (i = 0; i < n - 1; i++)
         for (j = i + 1; j < n; j++) {
             double es_real_energy = 0, es_self_intra_energy = 0;
+            if (c->cache) {
+                const size_t k = pair_index(n, i, j);
+                if (!c->cache->recalc[k]) { /* coulombic.c:160: stored values */
+                    potential += c->cache->es_real[k] - c->cache->es_intra[k];
+                    continue;
+                }
+                es_self_intra_energy = c->cache->es_intra[k]; /* persists unless recomputed (coulombic.c:181) */
+            }
             make_pair(c, i, j, &pr);
             if (!pr.frozen) {
                 double r = pr.rimg;
@@ -303,6 +382,10 @@ static double coulombic_real(const octx *c) {
                         es_real_energy += coulombic_real_FH(c, i, j, &pr, gaussian_term, erfc_term);
                 } else if (pr.es_excluded)
                     es_self_intra_energy = s->charge[i] * s->charge[j] * erf(alpha * pr.r) / pr.r;
+            }
+            if (c->cache) {
+                c->cache->es_real[pair_index(n, i, j)] = es_real_energy;
+                c->cache->es_intra[pair_index(n, i, j)] = es_self_intra_energy;
             }
             potential += es_real_energy - es_self_intra_energy;
         }
@@ -790,7 +873,42 @@ static double polar(const octx *c, orc_result *res, orc_vectors *vec) {
 }
 
 /* energy/energy.c:67-226 */
+struct orc_cache *orc_cache_create(int n) {
+    struct orc_cache *h = calloc(1, sizeof(*h));
+    h->n = n;
+    h->np = (size_t)n * (size_t)(n - 1) / 2;
+    h->d_prev = calloc(3 * h->np, sizeof(double));
+    h->r = calloc(h->np, sizeof(double));
+    h->rimg = calloc(h->np, sizeof(double));
+    h->dimg = calloc(3 * h->np, sizeof(double));
+    h->rd = calloc(h->np, sizeof(double));
+    h->lrc = calloc(h->np, sizeof(double));
+    h->es_real = calloc(h->np, sizeof(double));
+    h->es_intra = calloc(h->np, sizeof(double));
+    h->recalc = calloc(h->np, 1);
+    return h;
+}
+
+void orc_cache_free(struct orc_cache *h) {
+    if (!h) return;
+    free(h->d_prev);
+    free(h->r);
+    free(h->rimg);
+    free(h->dimg);
+    free(h->rd);
+    free(h->lrc);
+    free(h->es_real);
+    free(h->es_intra);
+    free(h->recalc);
+    free(h);
+}
+
 int orc_energy(const orc_system *sys, const orc_params *par, orc_result *res, orc_vectors *vec) {
+    return orc_energy_cached(sys, par, res, vec, NULL);
+}
+
+int orc_energy_cached(const orc_system *sys, const orc_params *par, orc_result *res, orc_vectors *vec,
+                      struct orc_cache *cache) {
     octx c;
     int i, n = sys->n;
     double rd_energy = 0, coulombic_energy = 0, polar_energy = 0, potential_energy = 0;
@@ -799,6 +917,8 @@ int orc_energy(const orc_system *sys, const orc_params *par, orc_result *res, or
     c.s = sys;
     c.p = par;
     c.n = n;
+    if (cache && cache->n != n) return -2;
+    c.cache = cache;
     c.midx = malloc(n * sizeof(int));
     c.molmass = malloc(n * sizeof(double));
 
@@ -828,6 +948,11 @@ int orc_energy(const orc_system *sys, const orc_params *par, orc_result *res, or
     res->cutoff = c.cutoff;
     res->ewald_alpha = c.ewald_alpha;
     res->polar_ewald_alpha = c.polar_ewald_alpha;
+
+    if (cache) {
+        pairs_update(&c);
+        cache->primed = 1;
+    }
 
     if (!(par->rd_only) && par->polarization) {
         polar_energy = polar(&c, res, vec);

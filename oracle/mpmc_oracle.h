@@ -96,6 +96,16 @@ typedef struct orc_vectors {
 /* full energy() restatement; returns 0 on success */
 int orc_energy(const orc_system *sys, const orc_params *par, orc_result *res, orc_vectors *vec);
 
+/* Same, keeping the reference's per-pair state between calls (pair list with cached geometry and pair
+ * energies): after a single-molecule move only the pairs whose displacement changed are recomputed, as
+ * in the reference (pairs.c:238-249, lj.c:182, coulombic.c:160).  Parameters and box must not change
+ * while a cache is in use.  This is the mode bench.py times as the CPU baseline. */
+typedef struct orc_cache orc_cache;
+orc_cache *orc_cache_create(int n);
+void orc_cache_free(orc_cache *cache);
+int orc_energy_cached(const orc_system *sys, const orc_params *par, orc_result *res, orc_vectors *vec,
+                      orc_cache *cache);
+
 /* pieces, for per-term tests */
 void orc_pbc(const double basis[3][3], double cutoff_in, double *volume, double recip[3][3], double *cutoff);
 void orc_minimum_image(const double basis[3][3], const double recip[3][3], const double *pi, const double *pj,

@@ -110,6 +110,12 @@ def lib():
         _lib = C.CDLL(_LIB)
         _lib.orc_energy.restype = C.c_int
         _lib.orc_energy.argtypes = [C.POINTER(OrcSystem), C.POINTER(OrcParams), C.POINTER(OrcResult), C.c_void_p]
+        _lib.orc_energy_cached.restype = C.c_int
+        _lib.orc_energy_cached.argtypes = [C.POINTER(OrcSystem), C.POINTER(OrcParams), C.POINTER(OrcResult), C.c_void_p,
+                                           C.c_void_p]
+        _lib.orc_cache_create.restype = C.c_void_p
+        _lib.orc_cache_create.argtypes = [C.c_int]
+        _lib.orc_cache_free.argtypes = [C.c_void_p]
         _lib.orc_default_params.argtypes = [C.POINTER(OrcParams)]
         _lib.orc_kvector_count.restype = C.c_int
         _lib.orc_kvector_count.argtypes = [C.c_int]
@@ -129,7 +135,22 @@ def make_params(**kw):
     return p
 
 
-def energy(system, params, want_vectors=False, want_A=False):
+class Cache:
+    """Per-pair state kept between calls, like the reference's pair list (see mpmc_oracle.h)."""
+
+    def __init__(self, n):
+        self.ptr = C.c_void_p(lib().orc_cache_create(int(n)))
+
+    def close(self):
+        if self.ptr:
+            lib().orc_cache_free(self.ptr)
+            self.ptr = C.c_void_p()
+
+    def __del__(self):
+        self.close()
+
+
+def energy(system, params, want_vectors=False, want_A=False, cache=None):
     """system: dict with pos[n,3], charge, alpha, epsilon, sigma, mass, molecule, frozen, basis[3,3].
     params: dict of reference config keywords (see OrcParams).  Returns dict."""
     n = int(len(system["charge"]))
@@ -168,7 +189,10 @@ def energy(system, params, want_vectors=False, want_A=False):
             out["A_matrix"] = np.zeros((3 * n, 3 * n))
             v.A_matrix = out["A_matrix"].ctypes.data
         vec_ptr = C.addressof(v)
-    rc = lib().orc_energy(C.byref(s), C.byref(p), C.byref(r), vec_ptr)
+    if cache is not None:
+        rc = lib().orc_energy_cached(C.byref(s), C.byref(p), C.byref(r), vec_ptr, cache.ptr)
+    else:
+        rc = lib().orc_energy(C.byref(s), C.byref(p), C.byref(r), vec_ptr)
     if rc != 0:
         raise RuntimeError("orc_energy failed: %d" % rc)
     for f, _ in OrcResult._fields_:

@@ -43,3 +43,23 @@ def test_oracle_reproduces_reference_digits(name):
 def test_kvector_count():
     # 709 vectors at kmax = 7
     assert oracle.lib().orc_kvector_count(7) == 709
+
+
+def test_cached_oracle_equals_full_recompute_bitwise():
+    """The pair-state cache (what the reference keeps in its pair list between steps) must not change a bit."""
+    from mpmc_amd import synth
+
+    s = synth.s_pol(160)
+    p = dict(synth.FLAGS_POL_PRODUCTION)
+    cache = oracle.Cache(160)
+    rng = np.random.default_rng(3)
+    pos = s["pos"].copy()
+    for _ in range(5):
+        s2 = dict(s, pos=pos.copy())
+        a = oracle.energy(s2, p)
+        b = oracle.energy(s2, p, cache=cache)
+        for k in ("energy", "rd_energy", "coulombic_energy", "es_real", "polarization_energy"):
+            assert a[k] == b[k], k
+        m = 5 * rng.integers(0, 32)
+        pos[m:m + 5] += rng.normal(scale=0.2, size=3)
+    cache.close()
