@@ -363,3 +363,71 @@ def test_rccl_single_rank_allreduce():
     assert np.array_equal(v, np.arange(8, dtype=np.float64))
     lib.mpmc_hip_comm_destroy(comm)
     eng.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json's largest size (16 384 atoms): the oracle cannot follow there in seconds, so parity is
+# carried by size-independent properties anchored on a size the oracle does check.
+# ---------------------------------------------------------------------------------------------
+def _supercell(s, k):
+    L = s["basis"][0, 0]
+    shifts = [np.array([a, b, c]) * L for a in range(k) for b in range(k) for c in range(k)]
+    n = len(s["charge"])
+    out = {key: np.concatenate([s[key]] * len(shifts)) for key in ("charge", "alpha", "epsilon", "sigma", "mass", "frozen")}
+    out["pos"] = np.concatenate([s["pos"] + sh for sh in shifts])
+    nmol = int(s["molecule"].max())
+    out["molecule"] = np.concatenate([s["molecule"] + i * nmol for i in range(len(shifts))]).astype(np.int32)
+    out["basis"] = s["basis"] * k
+    return out
+
+
+def test_16384_atoms_supercell_additivity_lj_and_real_space():
+    """A 2x2x2 supercell of a 2048-atom box (= 16 384 atoms) at the SAME cutoff has 8x the LJ pair energy
+    (incl. Feynman-Hibbs) and 8x the real-space Ewald sum; the small box is checked against the oracle.
+    (rd_lrc is off here: the reference's long-range correction sums N(N+1)/2 identical terms over V and is
+    therefore not extensive.)"""
+    small = synth.s_es(2048)
+    rc = 0.45 * small["basis"][0, 0]
+    p = dict(temperature=100.0, pbc_cutoff=rc, ewald_alpha_set=1, ewald_alpha=3.5 / rc, feynman_hibbs=1,
+             feynman_hibbs_order=4, rd_lrc=0)
+    e_small = run_engine(small, p)
+    check_energies(e_small, oracle.energy(small, p))
+    big = _supercell(small, 2)
+    assert len(big["charge"]) == 16384
+    e_big = run_engine(big, p)
+    assert rel(e_big["rd_energy"], 8 * e_small["rd_energy"]) < 1e-10
+    assert rel(e_big["es_real"], 8 * e_small["es_real"]) < 1e-10
+    assert rel(e_big["es_self"], 8 * e_small["es_self"]) < 1e-12
+
+
+def test_16384_atoms_polarizable_invariances():
+    """Full polarizable energy at 16 384 atoms: (a) translating a molecule by a lattice vector changes no
+    term (minimum image + Ewald periodicity; the reciprocal sum uses un-wrapped coordinates, so this
+    exercises exp(i k.L) = 1 as well); (b) A resident + incremental update gives bitwise the same
+    energies as a fresh context; (c) symmetric and full-matrix sweeps agree."""
+    s = synth.s_pol(16384)
+    p = dict(temperature=77.0, polarization=1, polar_damp=2.1304, polar_max_iter=4, feynman_hibbs=1,
+             feynman_hibbs_order=4)
+    eng = engine.Engine(16384)
+    eng.load_system(s, p)
+    e0 = eng.energy()
+    assert e0["status"] == 0 and e0["polar_iterations"] == 4
+    L = s["basis"][0]
+    moved = s["pos"][100:105] + L  # one BSSP molecule, one lattice vector along a
+    eng.update_atoms(100, moved)
+    e1 = eng.energy()
+    for k in ("rd_energy", "es_real", "es_self", "polarization_energy"):
+        assert rel(e1[k], e0[k]) < 1e-11, k
+    assert abs(e1["es_recip"] - e0["es_recip"]) < 1e-9 * abs(e0["es_real"])
+    s2 = dict(s)
+    s2["pos"] = s["pos"].copy()
+    s2["pos"][100:105] = moved
+    fresh = engine.Engine(16384)
+    fresh.load_system(s2, p)
+    e2 = fresh.energy()
+    assert e2["energy"] == e1["energy"] and e2["polarization_energy"] == e1["polarization_energy"]
+    fresh.set_option("symmetric_sweep", 0)
+    e3 = fresh.energy()
+    assert rel(e3["polarization_energy"], e2["polarization_energy"]) < 1e-11
+    eng.close()
+    fresh.close()
