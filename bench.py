@@ -4,7 +4,7 @@
 One "step" = one single-molecule displacement (translate + rotate, reference
 src/mc/mc_moves.c:378-488) + one energy() on the device through the C ABI + Metropolis
 (reference src/mc/mc.c:294-353), exactly what the reference does per step; the loop itself is the
-C host layer of host/ (system_t, energy(), checkpoint/make_move/restore), called via ctypes.  Workload: the
+C host layer of mpmc_amd/host/ (system_t, energy(), checkpoint/make_move/restore), called via ctypes.  Workload: the
 4096-atom PCN-61 cell + 416 BSSP H2 of tests/golden/pcn61_bssp_4096.npz with the flags of the
 reference's sample_configs_gpu/3_PCN61/iter.inp run as NVT (Jacobi x4, cutoff 8 A, FH 4th order)
 -- BASELINE.json configs[3]; `--workload` selects the synthetic boxes instead.
@@ -112,7 +112,7 @@ def main():
 
     system, flags, label = load_workload(args.workload)
     n = len(system["charge"])
-    # host control stays in C: system_t + energy() + the NVT chain of host/ drive the engine through the C ABI
+    # host control stays in C: system_t + energy() + the NVT chain of mpmc_amd/host/ drive the engine through the C ABI
     chain = host.HostSystem(system, flags, device=local_rank, seed=args.seed + rank)
     avg = WalkerAverages(dist=dist, device=dev)
     chain.energy()  # creates the device context, uploads the configuration

@@ -6,7 +6,7 @@
  * reference's C host code (src/energy/energy.c, where `#ifdef CUDA` spawns
  * `polar_cuda()` today, energy.c:108-129 and :181-186) binds these entry points
  * directly; INTEGRATION.md shows the patch.  The same library is what the
- * repo's own host layer (host/ directory, mirroring system_t/energy()) and the Python
+ * repo's own host layer (mpmc_amd/host/ directory, mirroring system_t/energy()) and the Python
  * tests (ctypes) call.
  *
  * Conventions

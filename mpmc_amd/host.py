@@ -1,4 +1,4 @@
-"""ctypes binding of the C host layer (host/libmpmc_host.so): system_t, energy(), mc() -- the mirror
+"""ctypes binding of the C host layer (mpmc_amd/host/libmpmc_host.so): system_t, energy(), mc() -- the mirror
 of the reference's host interface that sits above the C ABI.  Plumbing for tests and bench.py."""
 import ctypes as C
 import os
@@ -8,8 +8,8 @@ import numpy as np
 from . import engine
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "host", "libmpmc_host.so")
-EXE_PATH = os.path.join(os.path.dirname(_HERE), "host", "mpmc_hip")
+LIB_PATH = os.path.join(_HERE, "host", "libmpmc_host.so")
+EXE_PATH = os.path.join(_HERE, "host", "mpmc_hip")
 
 _lib = None
 
@@ -19,7 +19,7 @@ def load():
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
-        raise RuntimeError("host/libmpmc_host.so is not built (run __graft_entry__.build())")
+        raise RuntimeError("mpmc_amd/host/libmpmc_host.so is not built (run __graft_entry__.build())")
     engine.load()  # libmpmc_hip.so first (also found through the rpath)
     lib = C.CDLL(LIB_PATH)
     vp = C.c_void_p

@@ -16,7 +16,7 @@
 
 #include <stdio.h>
 
-#include "../include/mpmc_hip.h"
+#include "../../include/mpmc_hip.h"
 
 #ifdef __cplusplus
 extern "C" {

@@ -1,4 +1,4 @@
-"""CPU-only tests of the C host layer (host/): RNG stream, config + PQR readers, moves, list flattening.
+"""CPU-only tests of the C host layer (mpmc_amd/host/): RNG stream, config + PQR readers, moves, list flattening.
 energy() itself needs the GPU and is covered in test_gpu_host.py."""
 import ctypes as C
 import os
