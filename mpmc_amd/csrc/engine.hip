@@ -785,7 +785,15 @@ extern "C" int mpmc_hip_energy(mpmc_hip_ctx *c, mpmc_hip_result *out) {
     HIPCHK(hipStreamSynchronize(c->stream));
     const bool gs_timeout = (c->h_gserr[0] | c->h_gserr[1]) != 0;
     c->gs_used[0] = c->gs_used[1] = false;
-    if (gs_timeout) return fail("MPMC_HIP: persistent Gauss-Seidel kernel gave up waiting on a hand-off (spin limit)");
+    if (gs_timeout) {
+        unsigned dbg[8] = {0};
+        hipMemcpy(dbg, c->view[c->h_gserr[1] ? 1 : 0].gsflags, sizeof(dbg), hipMemcpyDeviceToHost);
+        return fail("MPMC_HIP: persistent Gauss-Seidel kernel gave up waiting on a hand-off (spin limit): "
+                    "workgroup %u thread %u addr-lo 0x%x; ypart-lo 0x%x mu_new-lo 0x%x",
+                    dbg[2], dbg[3], dbg[4],
+                    (unsigned)((unsigned long long)c->view[c->h_gserr[1] ? 1 : 0].ypart & 0xffffffffu),
+                    (unsigned)((unsigned long long)c->view[c->h_gserr[1] ? 1 : 0].munew & 0xffffffffu));
+    }
     HIPCHK(hipGetLastError());
     c->timed = true;
     c->dirty_atoms.clear();

@@ -13,12 +13,11 @@
 // variant that also kept the neighbour tile T(t+1,t) (196 KB) in the spine spent ~12 us per block
 // just fetching; handing that tile to the owner costs one flag round trip (~4 us) instead.
 //
-// Cross-workgroup hand-offs follow the gfx950 recipe (cdna_hip_programming.md, Guideline 16):
-// payload written with agent-scope relaxed atomic stores (write-through, sc1), every storing wave
-// drains (s_waitcnt vmcnt(0)), workgroup barrier, ONE lane stores the flag; consumers poll that one
-// word with relaxed agent-scope loads (+ s_sleep), then read the payload with agent-scope loads, which
-// bypass the (never refreshed) L1.  Dependencies are acyclic (ydone[t] needs ready >= t-1, which
-// needs ydone[<= t-2]); every spin is bounded and raises an error word instead of hanging.
+// Cross-workgroup hand-offs follow the gfx950 rules (cdna_hip_programming.md, Guideline 16) in the
+// data-is-the-flag form described at poll_value(): agent-scope write-through 8-byte stores, agent-scope
+// polling loads that bypass the (never refreshed) L1, no plain access to handed-off data.
+// Dependencies are acyclic (ypart_t needs mu of blocks < t, mu_t needs ypart_t); every spin is
+// bounded and raises an error word instead of hanging.
 // Results do not depend on placement or timing: each sum has a fixed order.
 #pragma once
 #include "device_common.h"
@@ -33,8 +32,8 @@ struct GsPersist {
     double *y;        // in: upper-triangle part (gs_upper_kernel); out: E_induced at update time
     double *mu_new;   // out
     double *ypart;    // [nb][192]
-    unsigned *flags;  // [0] blocks solved, [1] error, [2 + t] ydone[t]; zeroed before every launch
-    int debug;        // timing experiments only: 2 = spine does not wait for owners (WRONG results)
+    unsigned *flags;  // [1] error word (zeroed before every launch); mu_new and ypart are pre-filled with kGsSentinel
+    int debug;        // reserved
 };
 
 constexpr int kGsPairs = kGsBlock * (kGsBlock - 1) / 2;       // 2016
@@ -53,15 +52,30 @@ __device__ __forceinline__ double ld_agent(const double *p) {
                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 
-// one lane polls until *flag >= target; false on timeout or when another workgroup raised the error word
-__device__ __forceinline__ bool spin_ge(unsigned *flag, unsigned target, unsigned *err) {
+// Data-is-the-flag hand-off (Guideline 16, R2 granule form with the value as its own tag): mu_new and
+// ypart are pre-filled with a sentinel bit pattern (a NaN no arithmetic produces); the producer
+// writes each double with ONE agent-scope (sc1, write-through) 8-byte store and does not drain or
+// raise a flag; every consumer lane polls its own element with agent-scope loads (which bypass
+// L1) until it differs from the sentinel.  8-byte stores are single-copy atomic, so a value is never
+// seen torn.  One-way latency ~1 us instead of ~3.5 us for payload + drain + flag + poll + reload.
+constexpr unsigned long long kGsSentinel = 0x7ff8dead7ff8deadull;  // both 32-bit halves equal: memsetD32
+
+__device__ __forceinline__ double poll_value(const double *p, unsigned *err, bool &ok) {
+    const unsigned long long *q = reinterpret_cast<const unsigned long long *>(p);
     for (unsigned it = 0; it < kGsSpinLimit; ++it) {
-        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
-        if ((it & 63u) == 63u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
-        __builtin_amdgcn_s_sleep(2);
+        const unsigned long long v = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v != kGsSentinel) return __longlong_as_double((long long)v);
+        if ((it & 255u) == 255u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        __builtin_amdgcn_s_sleep(1);
     }
-    __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return false;
+    if (__hip_atomic_exchange(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        // first to give up: leave a breadcrumb (which workgroup, which thread, low address bits)
+        err[1] = blockIdx.x;
+        err[2] = threadIdx.x;
+        err[3] = (unsigned)(reinterpret_cast<unsigned long long>(p) & 0xffffffffu);
+    }
+    ok = false;
+    return 0.0;
 }
 
 // 6 unique elements of T_jl from row-block j (rows 3j..3j+2), columns 3l..3l+2
@@ -79,9 +93,12 @@ __device__ void gs_owner(const GsPersist &p, int first, int stride, double *lds)
     double *smu = lds;                 // [192]
     double *part = lds + 3 * kGsBlock; // [8][3][64]
     __shared__ int s_ok;
-    unsigned known = 0;                // blocks known to be solved
+    if (threadIdx.x == 0) s_ok = 1;
+    __syncthreads();
     for (int t = first; t < p.nb; t += stride) {
         const int k = t * kGsBlock + lane;  // this lane's target atom
+        // upper-triangle part of this block's field (previous kernel): fetched now, off the critical path
+        const double yu0 = p.y[3 * k], yu1 = p.y[3 * k + 1], yu2 = p.y[3 * k + 2];
         double a0 = 0.0, a1 = 0.0, a2 = 0.0;
         for (int s = 0; s + 1 <= t; ++s) {
             // tile loads first: they do not depend on the dipoles and hide behind the wait
@@ -89,17 +106,13 @@ __device__ void gs_owner(const GsPersist &p, int first, int stride, double *lds)
             const double *base = p.A + (size_t)(3 * (s * kGsBlock + 8 * w)) * p.lda + 3 * (size_t)k;
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) load_tensor6(base + (size_t)(3 * jj) * p.lda, (size_t)p.lda, tt[jj]);
-            if (known < (unsigned)(s + 1)) {
-                if (threadIdx.x == 0) {
-                    s_ok = spin_ge(p.flags, (unsigned)(s + 1), p.flags + 1) ? 1 : 0;
-                }
-                __syncthreads();
-                if (!s_ok) return;
-                known = (unsigned)(s + 1);
-            }
             __syncthreads();  // smu free
-            if (threadIdx.x < 3 * kGsBlock) smu[threadIdx.x] = ld_agent(p.mu_new + 3 * s * kGsBlock + threadIdx.x);
+            bool ok = true;
+            if (threadIdx.x < 3 * kGsBlock)
+                smu[threadIdx.x] = poll_value(p.mu_new + 3 * s * kGsBlock + threadIdx.x, p.flags + 1, ok);
+            if (!ok) s_ok = 0;
             __syncthreads();
+            if (!s_ok) return;
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) {
                 const double mx = smu[3 * (8 * w + jj)], my = smu[3 * (8 * w + jj) + 1], mz = smu[3 * (8 * w + jj) + 2];
@@ -114,15 +127,14 @@ __device__ void gs_owner(const GsPersist &p, int first, int stride, double *lds)
         part[(w * 3 + 2) * kGsBlock + lane] = a2;
         __syncthreads();
         if (w == 0) {
+            const double yu[3] = {yu0, yu1, yu2};
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 double sum = 0.0;
 #pragma unroll
                 for (int g = 0; g < 8; ++g) sum += part[(g * 3 + q) * kGsBlock + lane];
-                st_agent(p.ypart + (size_t)t * 3 * kGsBlock + 3 * lane + q, p.y[3 * k + q] - sum);
+                st_agent(p.ypart + (size_t)t * 3 * kGsBlock + 3 * lane + q, yu[q] - sum);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) __hip_atomic_store(p.flags + 2 + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
     }
@@ -132,7 +144,6 @@ __device__ void gs_spine(const GsPersist &p, double *lds) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     double *tile = lds;                                 // [12096] strictly-upper part of the diagonal tile
     double *smu = lds + kGsTileDoubles;                 // [192] mu of the block just solved
-    double *part = smu + 3 * kGsBlock;                  // [7][3][64] neighbour partial sums
     __shared__ int s_ok;
     const size_t lda = (size_t)p.lda;
 
@@ -190,17 +201,17 @@ __device__ void gs_spine(const GsPersist &p, double *lds) {
         if (w != 0 && t + 1 < p.nb) prefetch(t + 1);
 
         if (w == 0) {
-            if (lane == 0) s_ok = (p.debug == 2) ? 1 : (spin_ge(p.flags + 2 + t, 1u, p.flags + 1) ? 1 : 0);
-            // single wave: program order keeps the loads below behind the poll
             const int k = t * kGsBlock + lane;
-            double y0 = 0.0, y1 = 0.0, y2 = 0.0;
-            const bool ok = __shfl(s_ok, 0, 64) != 0;
+            // everything that does not depend on the hand-off is fetched before the poll
+            const double al = p.alpha[k];
+            const double ae0 = al * p.es[3 * k], ae1 = al * p.es[3 * k + 1], ae2 = al * p.es[3 * k + 2];
+            bool okl = true;
+            double y0 = poll_value(p.ypart + (size_t)t * 3 * kGsBlock + 3 * lane, p.flags + 1, okl);
+            double y1 = poll_value(p.ypart + (size_t)t * 3 * kGsBlock + 3 * lane + 1, p.flags + 1, okl);
+            double y2 = poll_value(p.ypart + (size_t)t * 3 * kGsBlock + 3 * lane + 2, p.flags + 1, okl);
+            const bool ok = __all(okl);
+            if (lane == 0) s_ok = ok ? 1 : 0;
             if (ok) {
-                y0 = ld_agent(p.ypart + (size_t)t * 3 * kGsBlock + 3 * lane);
-                y1 = ld_agent(p.ypart + (size_t)t * 3 * kGsBlock + 3 * lane + 1);
-                y2 = ld_agent(p.ypart + (size_t)t * 3 * kGsBlock + 3 * lane + 2);
-                const double al = p.alpha[k];
-                const double ae0 = al * p.es[3 * k], ae1 = al * p.es[3 * k + 1], ae2 = al * p.es[3 * k + 2];
                 // The chain is issue-bound (one wave, ~30 instructions per step), so it is fully unrolled:
                 // lane masks, LDS offsets and readlane indices become immediates.  A lane's y stops changing
                 // once its own step has passed, so its dipole al*(E + y) is simply evaluated after the loop;
@@ -249,9 +260,6 @@ __device__ void gs_spine(const GsPersist &p, double *lds) {
                 p.y[3 * k] = y0;  // E_induced of the atom when it was updated (thole_iterative.c:44-46)
                 p.y[3 * k + 1] = y1;
                 p.y[3 * k + 2] = y2;
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0)
-                    __hip_atomic_store(p.flags, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         __syncthreads();
