@@ -115,9 +115,9 @@ void mpmc_hip_destroy(mpmc_hip_ctx *ctx);
  *                          polarization chain;
  *   "symmetric_sweep"     (default 1): Jacobi/Palmo sweeps read only the upper triangle of A and use
  *                          every element for both products (half the HBM bytes); 0 = full-matrix sweep;
- *   "timing"              (default 1): 0 = record no HIP events; 1 = time the sweep kernels and the whole
- *                          call only (4-10 event pairs); 2 = time every kernel class (each event pair costs
- *                          a few microseconds of stream time: ~13 % of a 0.6 ms step);
+ *   "timing"              (default 1): 0 = record no HIP events; 1 = time the sweep kernels of every 4th
+ *                          call; 2 = time every kernel class of every call (each event pair costs
+ *                          ~4 microseconds of stream time: ~13 % of a 0.6 ms step);
  *   "persistent_gs"       (default 1): Gauss-Seidel lower-triangle phase as one persistent kernel
  *                          (spine + owner workgroups); 0 = two launches per 64-atom block. */
 int mpmc_hip_set_option(mpmc_hip_ctx *ctx, const char *name, int value);

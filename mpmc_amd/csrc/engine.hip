@@ -126,6 +126,8 @@ struct mpmc_hip_ctx {
            *d_tmp3 = nullptr;
     unsigned long long *d_errmax = nullptr;
     bool have_polar_result = false;
+    MoveList pending;               // coordinates handed over by update_atoms(), applied at the next energy()
+    unsigned long long energy_calls = 0;
     std::vector<int> dirty_atoms;   // atoms moved by update_atoms() since the last energy()
     bool all_dirty = true;
     int opt_incremental = 1, opt_overlap = 1, opt_symmetric = 1, opt_persistent_gs = 1;
@@ -217,7 +219,9 @@ struct ScopedTimer {
     TimeRec r;
     bool on;
     ScopedTimer(mpmc_hip_ctx *ctx, int cls, hipStream_t st = nullptr) : c(ctx), s(st ? st : ctx->stream), on(false) {
-        const bool wanted = c->opt_timing >= 2 || (c->opt_timing == 1 && cls == 4 /* T_SWEEP */);
+        // timing 1: the sweep kernels of every 4th call (an event pair costs ~4 us of stream time)
+        const bool wanted = c->opt_timing >= 2 ||
+                            (c->opt_timing == 1 && cls == 4 /* T_SWEEP */ && (c->energy_calls & 3ull) == 0ull);
         if (wanted && c->ev_next + 2 <= c->ev_pool.size()) {
             r.cls = cls;
             r.a = c->ev_pool[c->ev_next++];
@@ -269,6 +273,7 @@ extern "C" int mpmc_hip_create(mpmc_hip_ctx **out, int device, int max_atoms) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail("MPMC_HIP: no HIP device available (this engine has no CPU fallback)");
     if (device < 0 || device >= ndev) return fail("MPMC_HIP: device %d out of range (%d present)", device, ndev);
+    (void)hipSetDeviceFlags(hipDeviceScheduleSpin);  // low wake-up latency on the per-step synchronisation
     HIPCHK(hipSetDevice(device));
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
@@ -514,6 +519,7 @@ extern "C" int mpmc_hip_upload(mpmc_hip_ctx *c, int n, const double *x, const do
     c->lrc_valid = false;
     c->perm.assign(n, 0);
     std::iota(c->perm.begin(), c->perm.end(), 0);
+    c->pending.n = 0;
     // view 0: polarizable atoms in atom order
     SweepView &v0 = c->view[0];
     v0.h_idx.clear();
@@ -535,6 +541,15 @@ extern "C" int mpmc_hip_upload(mpmc_hip_ctx *c, int n, const double *x, const do
     return 0;
 }
 
+// apply the queued single-molecule moves (kept in order with any staged copies)
+static int flush_moves(mpmc_hip_ctx *c) {
+    if (c->pending.n > 0) {
+        hipLaunchKernelGGL(apply_moves_kernel, dim3(1), dim3(64), 0, c->stream, c->pending, c->d_x, c->d_y, c->d_z);
+        c->pending.n = 0;
+    }
+    return 0;
+}
+
 extern "C" int mpmc_hip_update_atoms(mpmc_hip_ctx *c, int first, int count, const double *x, const double *y,
                                      const double *z) {
     if (!c || !c->have_atoms) return fail("MPMC_HIP: update_atoms: no configuration uploaded");
@@ -543,7 +558,34 @@ extern "C" int mpmc_hip_update_atoms(mpmc_hip_ctx *c, int first, int count, cons
     if (!x || !y || !z) return fail("MPMC_HIP: update_atoms: null array");
     HIPCHK(hipSetDevice(c->device));
     const size_t b = count * sizeof(double);
-    if ((size_t)(3 * count) <= c->stage_cap) {
+    bool queued = false;
+    if (count <= kMaxMoves) {
+        // a single-molecule move: queue it for one argument-carried launch at the next energy()
+        MoveList &m = c->pending;
+        int need = 0;
+        for (int i = 0; i < count; ++i) {
+            bool found = false;
+            for (int k = 0; k < m.n; ++k) found |= (m.idx[k] == first + i);
+            need += !found;
+        }
+        if (m.n + need <= kMaxMoves) {
+            for (int i = 0; i < count; ++i) {
+                int slot = -1;
+                for (int k = 0; k < m.n; ++k)
+                    if (m.idx[k] == first + i) slot = k;
+                if (slot < 0) slot = m.n++;
+                m.idx[slot] = first + i;
+                m.x[slot] = x[i];
+                m.y[slot] = y[i];
+                m.z[slot] = z[i];
+            }
+            queued = true;
+        }
+    }
+    if (queued) {
+        // nothing to launch yet
+    } else if ((size_t)(3 * count) <= c->stage_cap) {
+        if (flush_moves(c)) return -1;
         // small delta (one molecule): stage in pinned memory so the copies are truly asynchronous and the
         // caller's buffers are free at once; the ring is recycled after the next energy() has synchronised
         if (c->stage_used + 3 * (size_t)count > c->stage_cap) {
@@ -559,6 +601,7 @@ extern "C" int mpmc_hip_update_atoms(mpmc_hip_ctx *c, int first, int count, cons
         HIPCHK(hipMemcpyAsync(c->d_y + first, s + count, b, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(c->d_z + first, s + 2 * count, b, hipMemcpyHostToDevice, c->stream));
     } else {
+        if (flush_moves(c)) return -1;
         HIPCHK(hipMemcpyAsync(c->d_x + first, x, b, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(c->d_y + first, y, b, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(c->d_z + first, z, b, hipMemcpyHostToDevice, c->stream));
@@ -698,6 +741,8 @@ extern "C" int mpmc_hip_energy(mpmc_hip_ctx *c, mpmc_hip_result *out) {
     memset(out, 0, sizeof(*out));
     c->ev_next = 0;
     c->recs.clear();
+    ++c->energy_calls;
+    if (flush_moves(c)) return -1;
     hipEventRecord(c->ev_first, c->stream);
 
     const DevAtoms a = dev_atoms(c);
@@ -846,6 +891,7 @@ extern "C" int mpmc_hip_download_amatrix(mpmc_hip_ctx *c, double *A) {
     if (!c || !c->have_atoms || !c->have_box || !A) return fail("MPMC_HIP: download_amatrix: no configuration");
     HIPCHK(hipSetDevice(c->device));
     const size_t n3 = 3 * (size_t)c->n, lda = 3 * (size_t)c->npad;
+    if (flush_moves(c)) return -1;
     double *dA = nullptr;
     HIPCHK(hipMalloc((void **)&dA, lda * lda * sizeof(double)));
     hipLaunchKernelGGL(build_amatrix_kernel, dim3(c->npad / 128, c->npad / kARows), dim3(64), 0, c->stream,

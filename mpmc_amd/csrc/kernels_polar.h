@@ -304,6 +304,25 @@ __global__ __launch_bounds__(64) void build_amatrix_kernel(DevAtoms a, DevBox bx
 // the reference's O(N^2) rebuild (thole_matrix.c:58-143 every step).  Every rewritten entry is the
 // same function of the same coordinates as in a full build, hence bit-identical to it.
 // grid = (nvpad/128 [column tiles], ndirty); block = 64.
+// Coordinates of the atoms moved since the last energy(), by value in the kernel arguments: one tiny
+// launch replaces the 3-6 staged host-to-device copies (each a ~5 us copy kernel) of an MC move.
+constexpr int kMaxMoves = 32;
+struct MoveList {
+    int n;
+    int idx[kMaxMoves];
+    double x[kMaxMoves], y[kMaxMoves], z[kMaxMoves];
+};
+
+__global__ __launch_bounds__(64) void apply_moves_kernel(MoveList m, double *__restrict__ x, double *__restrict__ y,
+                                                          double *__restrict__ z) {
+    const int e = threadIdx.x;
+    if (e < m.n) {  // entries are unique per atom (the host merges repeated updates)
+        x[m.idx[e]] = m.x[e];
+        y[m.idx[e]] = m.y[e];
+        z[m.idx[e]] = m.z[e];
+    }
+}
+
 struct DirtyList {  // passed by value in the kernel arguments: no H2D copy on the step's critical path
     int slot[64];
 };

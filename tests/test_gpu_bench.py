@@ -26,4 +26,4 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0.2 < rf["frac"] < 1.0
-    assert rf["launches"] == 20 * 4  # Jacobi x4 per step, timed live with HIP events
+    assert 4 <= rf["launches"] <= 20 * 4 and rf["launches"] % 4 == 0  # Jacobi x4 per sampled step, HIP events
