@@ -759,66 +759,76 @@ extern "C" int mpmc_hip_energy(mpmc_hip_ctx *c, mpmc_hip_result *out) {
         hipStreamWaitEvent(sb, c->ev_fork, 0);
     }
 
-    // ---- LJ long-range correction: parameters + volume only => cached (lj.c:56-107)
-    if (P.rd_lrc) {
-        if (!c->lrc_valid) {
-            ScopedTimer t(c, T_OTHER, sb);
-            hipLaunchKernelGGL(lj_lrc_kernel, dim3(ntile, ntile), dim3(64), 0, sb, a, bx, c->d_pairpart);
-            hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, sb, c->d_pairpart, ntile * ntile, 1,
-                               c->d_res + R_LRC);
-            c->lrc_valid = true;
-        }
-    } else {
-        HIPCHK(hipMemsetAsync(c->d_res + R_LRC, 0, sizeof(double), sb));
-        c->lrc_valid = false;
-    }
-
-    // ---- fused pair kernel: LJ(+FH) and real-space Ewald(+FH, + intra-molecular screening)
-    {
-        ScopedTimer t(c, T_PAIR, sb);
-        PairParams pp;
-        pp.ewald_alpha = c->ewald_alpha;
-        pp.temperature = P.temperature;
-        pp.rd_only = P.rd_only;
-        pp.fh_order = P.feynman_hibbs ? P.feynman_hibbs_order : 0;
-        pp.wolf = P.wolf;
-        pp.erfaRoverR = std::erf(c->ewald_alpha * c->cutoff) / c->cutoff;
-        const dim3 grid(ntile, ntile), block(64);
-        if (pp.fh_order == 0)
-            hipLaunchKernelGGL(pair_rd_es_kernel<0>, grid, block, 0, sb, a, bx, pp, c->d_pairpart);
-        else if (pp.fh_order == 2)
-            hipLaunchKernelGGL(pair_rd_es_kernel<2>, grid, block, 0, sb, a, bx, pp, c->d_pairpart);
-        else
-            hipLaunchKernelGGL(pair_rd_es_kernel<4>, grid, block, 0, sb, a, bx, pp, c->d_pairpart);
-        hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, sb, c->d_pairpart, ntile * ntile,
-                           kPairChannels, c->d_res + R_RD_PAIR);
-    }
-
-    // ---- reciprocal + self (absent under Wolf summation, coulombic.c:27-28)
-    if (!P.rd_only && !P.wolf) {
-        ScopedTimer t(c, T_RECIP, sb);
-        if (c->nk > 0) {
-            hipLaunchKernelGGL(ewald_recip_kernel, dim3(c->nk), dim3(256), 0, sb, a, c->d_kvec, c->d_perk);
-            hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, sb, c->d_perk, c->nk, 1,
-                               c->d_res + R_RECIP);
-        } else {
-            HIPCHK(hipMemsetAsync(c->d_res + R_RECIP, 0, sizeof(double), sb));
-        }
-        hipLaunchKernelGGL(ewald_self_kernel, dim3(1), dim3(256), 0, sb, a, c->ewald_alpha, c->d_res + R_SELF);
-    } else {
-        HIPCHK(hipMemsetAsync(c->d_res + R_RECIP, 0, 2 * sizeof(double), sb));
-    }
-    if (c->opt_overlap) hipEventRecord(c->ev_join, sb);
-
-    // ---- polarization (main stream)
     const bool do_polar = !P.rd_only && P.polarization;
-    if (do_polar) {
-        if (run_polarization(c, a, bx, &polar_iterations, &iter_success)) return -1;
-    } else {
-        HIPCHK(hipMemsetAsync(c->d_res + R_UPOL, 0, 2 * sizeof(double), c->stream));
+    // Enqueue order: the host needs ~5 us per launch, and the polarization chain is the critical path, so
+    // with a fixed iteration count its ~15 launches go first and the side-stream kernels (which have
+    // ~200 us of slack) after; in precision mode the chain synchronises with the host every iteration, so
+    // the side stream is fed first.
+    const bool polar_first = do_polar && c->opt_overlap && P.polar_precision == 0.0;
+    for (int phase = 0; phase < 2; ++phase) {
+        const bool side_now = (phase == 0) ? !polar_first : polar_first;
+        if (side_now) {
+        // ---- LJ long-range correction: parameters + volume only => cached (lj.c:56-107)
+        if (P.rd_lrc) {
+            if (!c->lrc_valid) {
+                ScopedTimer t(c, T_OTHER, sb);
+                hipLaunchKernelGGL(lj_lrc_kernel, dim3(ntile, ntile), dim3(64), 0, sb, a, bx, c->d_pairpart);
+                hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, sb, c->d_pairpart, ntile * ntile, 1,
+                                   c->d_res + R_LRC);
+                c->lrc_valid = true;
+            }
+        } else {
+            HIPCHK(hipMemsetAsync(c->d_res + R_LRC, 0, sizeof(double), sb));
+            c->lrc_valid = false;
+        }
+
+        // ---- fused pair kernel: LJ(+FH) and real-space Ewald(+FH, + intra-molecular screening)
+        {
+            ScopedTimer t(c, T_PAIR, sb);
+            PairParams pp;
+            pp.ewald_alpha = c->ewald_alpha;
+            pp.temperature = P.temperature;
+            pp.rd_only = P.rd_only;
+            pp.fh_order = P.feynman_hibbs ? P.feynman_hibbs_order : 0;
+            pp.wolf = P.wolf;
+            pp.erfaRoverR = std::erf(c->ewald_alpha * c->cutoff) / c->cutoff;
+            const dim3 grid(ntile, ntile), block(64);
+            if (pp.fh_order == 0)
+                hipLaunchKernelGGL(pair_rd_es_kernel<0>, grid, block, 0, sb, a, bx, pp, c->d_pairpart);
+            else if (pp.fh_order == 2)
+                hipLaunchKernelGGL(pair_rd_es_kernel<2>, grid, block, 0, sb, a, bx, pp, c->d_pairpart);
+            else
+                hipLaunchKernelGGL(pair_rd_es_kernel<4>, grid, block, 0, sb, a, bx, pp, c->d_pairpart);
+            hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, sb, c->d_pairpart, ntile * ntile,
+                               kPairChannels, c->d_res + R_RD_PAIR);
+        }
+
+        // ---- reciprocal + self (absent under Wolf summation, coulombic.c:27-28)
+        if (!P.rd_only && !P.wolf) {
+            ScopedTimer t(c, T_RECIP, sb);
+            if (c->nk > 0) {
+                hipLaunchKernelGGL(ewald_recip_kernel, dim3(c->nk), dim3(256), 0, sb, a, c->d_kvec, c->d_perk);
+                hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, sb, c->d_perk, c->nk, 1,
+                                   c->d_res + R_RECIP);
+            } else {
+                HIPCHK(hipMemsetAsync(c->d_res + R_RECIP, 0, sizeof(double), sb));
+            }
+            hipLaunchKernelGGL(ewald_self_kernel, dim3(1), dim3(256), 0, sb, a, c->ewald_alpha, c->d_res + R_SELF);
+        } else {
+            HIPCHK(hipMemsetAsync(c->d_res + R_RECIP, 0, 2 * sizeof(double), sb));
+        }
+        if (c->opt_overlap) hipEventRecord(c->ev_join, sb);
+        } else {
+        // ---- polarization (main stream)
+        if (do_polar) {
+            if (run_polarization(c, a, bx, &polar_iterations, &iter_success)) return -1;
+        } else {
+            HIPCHK(hipMemsetAsync(c->d_res + R_UPOL, 0, 2 * sizeof(double), c->stream));
+        }
+        // the resident A only tracks moves while it is being maintained
+        if (!do_polar || P.polar_zodid) c->view[0].A_valid = false;
+        }
     }
-    // the resident A only tracks moves while it is being maintained
-    if (!do_polar || P.polar_zodid) c->view[0].A_valid = false;
     if (c->opt_overlap) hipStreamWaitEvent(c->stream, c->ev_join, 0);
     hipEventRecord(c->ev_last, c->stream);
     HIPCHK(hipMemcpyAsync(c->h_res, c->d_res, R_COUNT * sizeof(double), hipMemcpyDeviceToHost, c->stream));
