@@ -153,6 +153,7 @@ def main():
     sync()
     t0 = time.perf_counter()
     run(args.steps)
+    avg.summary()  # completes the last (asynchronous) walker all-reduce inside the timed region
     sync()
     elapsed = time.perf_counter() - t0
     acc = chain.timings()

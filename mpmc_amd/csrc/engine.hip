@@ -290,8 +290,14 @@ extern "C" int mpmc_hip_create(mpmc_hip_ctx **out, int device, int max_atoms) {
     c->num_cus = prop.multiProcessorCount;
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(gs_persistent_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, kGsPersistLds));
-    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    /* Two priority classes, so that the two streams never share a hardware queue whatever other streams
+     * the process holds (the runtime pools its queues per priority; with RCCL initialised first both
+     * streams otherwise land on one queue and the LJ/Ewald overlap is lost).  The polarization chain is
+     * the critical path and takes the higher priority. */
+    int prio_least = 0, prio_greatest = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    HIPCHK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest));
+    HIPCHK(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_least));
     HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
 #define DALLOC(ptr, count, type) HIPCHK(hipMalloc((void **)&(ptr), (count) * sizeof(type)))
@@ -338,7 +344,8 @@ extern "C" int mpmc_hip_create(mpmc_hip_ctx **out, int device, int max_atoms) {
     DALLOC(c->d_fieldpart, nchunk_max * 3 * np, double);
     DALLOC(c->d_res, R_COUNT, double);
 #undef DALLOC
-    HIPCHK(hipHostMalloc((void **)&c->h_res, R_COUNT * sizeof(double), hipHostMallocMapped));
+    HIPCHK(hipHostMalloc((void **)&c->h_res, (R_COUNT + 1) * sizeof(double), hipHostMallocMapped));
+    c->h_res[R_COUNT] = 0.0;
     HIPCHK(hipHostGetDevicePointer((void **)&c->h_res_dev, c->h_res, 0));
     HIPCHK(hipHostMalloc((void **)&c->h_err, sizeof(unsigned long long), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&c->h_gserr, 2 * sizeof(unsigned), hipHostMallocDefault));
@@ -729,8 +736,12 @@ static int ensure_view_matrix(SweepView &v) {
 #include "engine_polar.inc"
 
 // the 16-double result record goes straight into mapped pinned host memory (no copy engine / copy kernel)
-__global__ void publish_result_kernel(const double *__restrict__ d_res, double *__restrict__ h_res, int n) {
+// followed by a sequence number the host spins on (no dependence on the device's sync-scheduling mode)
+__global__ void publish_result_kernel(const double *__restrict__ d_res, volatile double *__restrict__ h_res, int n,
+                                      double seq) {
     if ((int)threadIdx.x < n) h_res[threadIdx.x] = d_res[threadIdx.x];
+    __threadfence_system();
+    if (threadIdx.x == 0) h_res[n] = seq;
 }
 
 extern "C" int mpmc_hip_energy(mpmc_hip_ctx *c, mpmc_hip_result *out) {
@@ -840,13 +851,29 @@ extern "C" int mpmc_hip_energy(mpmc_hip_ctx *c, mpmc_hip_result *out) {
     if (c->opt_overlap) hipStreamWaitEvent(c->stream, c->ev_join, 0);
     const bool timed_call = c->opt_timing >= 2 || (c->opt_timing == 1 && (c->energy_calls & 3ull) == 0ull);
     if (timed_call) hipEventRecord(c->ev_last, c->stream);
-    hipLaunchKernelGGL(publish_result_kernel, dim3(1), dim3(64), 0, c->stream, c->d_res, c->h_res_dev, (int)R_COUNT);
+    hipLaunchKernelGGL(publish_result_kernel, dim3(1), dim3(64), 0, c->stream, c->d_res, c->h_res_dev, (int)R_COUNT,
+                       (double)c->energy_calls);
     c->h_gserr[0] = c->h_gserr[1] = 0;
     for (int v = 0; v < 2; ++v)
         if (c->gs_used[v])
             HIPCHK(hipMemcpyAsync(c->h_gserr + v, c->view[v].gsflags + 1, sizeof(unsigned), hipMemcpyDeviceToHost,
                                   c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    {
+        // spin on the sequence number the publish kernel writes last; fall back to a stream sync if it
+        // does not show up (also surfaces launch errors)
+        volatile double *seq = c->h_res + R_COUNT;
+        const double want = (double)c->energy_calls;
+        bool seen = false;
+        for (unsigned long long spins = 0; spins < 2000000000ull; ++spins) {
+            if (*seq == want) {
+                seen = true;
+                break;
+            }
+            if ((spins & 0xfffffull) == 0xfffffull && hipStreamQuery(c->stream) != hipErrorNotReady) break;
+            __builtin_ia32_pause();
+        }
+        if (!seen) HIPCHK(hipStreamSynchronize(c->stream));
+    }
     const bool gs_timeout = (c->h_gserr[0] | c->h_gserr[1]) != 0;
     c->gs_used[0] = c->gs_used[1] = false;
     if (gs_timeout) {

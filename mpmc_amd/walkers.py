@@ -17,27 +17,46 @@ class WalkerAverages:
         self.device = device
         self.local = np.zeros(len(FIELDS))
         self.pooled = np.zeros(len(FIELDS))
-        self._buf = None
+        self._bufs = None
+        self._pending = None  # (work handle, buffer) of the all-reduce still in flight
+        self._k = 0
 
     def add(self, energy, rd, es, pol, iters, accepted):
         self.local += (1.0, energy, energy * energy, rd, es, pol, iters, accepted)
 
+    def _distributed(self):
+        return self.dist is not None and self.dist.is_initialized() and self.dist.get_world_size() > 1
+
+    def _finish_pending(self):
+        if self._pending is not None:
+            work, buf = self._pending
+            work.wait()
+            self.pooled += buf.cpu().numpy()
+            self._pending = None
+
     def reduce(self):
-        """Sum the interval's local sums over all walkers and fold them into the pooled totals."""
+        """Sum the interval's local sums over all walkers.  The collective is launched asynchronously and
+        folded into the pooled totals at the NEXT call (or at summary()): the averages are only reported,
+        never fed back into the chains, so the ~10 energy() calls of the next interval hide its latency
+        (the reference blocks in MPI_Gather here, mc.c:431)."""
         v = self.local.copy()
-        if self.dist is not None and self.dist.is_initialized() and self.dist.get_world_size() > 1:
+        self.local[:] = 0.0
+        if self._distributed():
             import torch
 
-            if self._buf is None:
-                self._buf = torch.zeros(len(FIELDS), dtype=torch.float64, device=self.device or "cpu")
-            self._buf.copy_(torch.from_numpy(v))
-            self.dist.all_reduce(self._buf)
-            v = self._buf.cpu().numpy()
-        self.pooled += v
-        self.local[:] = 0.0
-        return v
+            if self._bufs is None:
+                self._bufs = [torch.zeros(len(FIELDS), dtype=torch.float64, device=self.device or "cpu")
+                              for _ in range(2)]
+            self._finish_pending()
+            buf = self._bufs[self._k & 1]
+            self._k += 1
+            buf.copy_(torch.from_numpy(v))
+            self._pending = (self.dist.all_reduce(buf, async_op=True), buf)
+        else:
+            self.pooled += v
 
     def summary(self):
+        self._finish_pending()
         n = max(self.pooled[0], 1.0)
         mean = self.pooled[1] / n
         var = max(self.pooled[2] / n - mean * mean, 0.0)
