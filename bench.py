@@ -92,6 +92,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--full-sweep", action="store_true", help="A/B: stream the full matrix instead of its upper triangle")
     ap.add_argument("--full-rebuild", action="store_true", help="A/B: rebuild A from scratch every step")
+    ap.add_argument("--expanded-matrix", action="store_true",
+                    help="A/B: sweep over the expanded 3N x 3N matrix (72 B per pair) instead of pair coefficients (16 B)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -122,10 +124,11 @@ def main():
     if os.environ.get("MPMC_GS_DEBUG"):
         chain.energy()
         chain.set_option("persistent_gs", int(os.environ["MPMC_GS_DEBUG"]))
-    if args.full_sweep or args.full_rebuild:
+    if args.full_sweep or args.full_rebuild or args.expanded_matrix:
         chain.energy()  # creates the device context
         chain.set_option("symmetric_sweep", 0 if args.full_sweep else 1)
         chain.set_option("incremental_amatrix", 0 if args.full_rebuild else 1)
+        chain.set_option("pair_coefficients", 0 if (args.expanded_matrix or args.full_sweep) else 1)
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -171,21 +174,29 @@ def main():
     if rank == 0:
         value = world * args.steps / elapsed
         sweep_avg_ms = acc["sweep_ms"] / max(1, acc["sweep_count"])
-        # algorithmic bytes of one sweep launch (symv_kernel): the UPPER TRIANGLE of the polarizable
-        # block of A (symmetric; sites with alpha = 0 carry no dipole, so neither their rows nor their
-        # columns exist), fp64, read once, + mu in and the row/column partial sums out
+        # algorithmic bytes of one sweep launch (pair_sweep_kernel): one {c3, c5} coefficient pair (16 B, fp64)
+        # per unordered pair of polarizable sites, read once, + coordinates and dipoles in, field out.
+        # (sites with alpha = 0 carry no dipole, so neither their rows nor their columns exist)
         n_pol = int(np.count_nonzero(np.asarray(system["alpha"]) != 0.0))
         m3 = 3.0 * n_pol
-        sweep_bytes = m3 * (m3 + 1) / 2 * 8 + 3 * m3 * 8
-        sym_off = ((n_pol + 127) // 128 * 128) < 2048  # the engine's size threshold for the symmetric kernel
-        if args.full_sweep or sym_off:
+        expanded = args.expanded_matrix or args.full_sweep
+        sym_off = ((n_pol + 127) // 128 * 128) < 2048  # size threshold of the symmetric expanded-matrix kernel
+        if not expanded:
+            sweep_bytes = n_pol * (n_pol - 1) / 2 * 16 + 3 * m3 * 8
+            kernel_name = "pair_sweep_kernel"
+        elif args.full_sweep or sym_off:
             sweep_bytes = m3 * m3 * 8 + 5 * m3 * 8
+            kernel_name = "sweep_kernel<Jacobi>"
+        else:  # upper triangle of the expanded matrix
+            sweep_bytes = m3 * (m3 + 1) / 2 * 8 + 3 * m3 * 8
+            kernel_name = "symv_kernel"
         achieved = sweep_bytes / (sweep_avg_ms * 1e-3) / 1e9 if sweep_avg_ms > 0 else 0.0
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "sweep_pmc_latest.json")
         if os.path.exists(pmc) and args.workload == "pcn61_4096":
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                rec = json.load(open(pmc))
+                traffic = rec.get("hbm_bytes_per_launch") if kernel_name.split("<")[0] in rec.get("kernel", "") else None
             except Exception:
                 traffic = None
         out = {
@@ -205,8 +216,7 @@ def main():
                     "random MC moves",
             "config": {"workload": label, "n_atoms": n, "n_polarizable": n_pol, "walkers": world, "corrtime": args.corrtime,
                        "parallelism": "%d independent walkers, 1 per GPU" % world},
-            "roofline": {"kernel": ("sweep_kernel<Jacobi>" if (args.full_sweep or sym_off) else "symv_kernel") +
-                                   " (Thole field / dipole sweep)", "bound": "hbm",
+            "roofline": {"kernel": kernel_name + " (Thole field / dipole sweep)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": sweep_avg_ms, "launches": acc["sweep_count"],

@@ -29,6 +29,7 @@
 #include "kernels_gs.h"
 #include "kernels_gs_persistent.h"
 #include "kernels_symv.h"
+#include "kernels_coef.h"
 
 using namespace mpmc;
 
@@ -100,6 +101,9 @@ struct SweepView {
     double *A = nullptr;
     size_t Acap = 0;  // doubles
     bool A_valid = false;  // A matches the configuration as of the last energy() (minus `dirty` atoms)
+    double2 *C = nullptr;  // pair-coefficient tiles {c3, c5} (kernels_coef.h), the default sweep storage
+    size_t Ccap = 0;       // double2 elements
+    bool C_valid = false;
     int *d_slot = nullptr;  // device copy of slot_of_atom (padded with -1)
     std::vector<int> slot_of_atom;  // atom index -> view slot, -1 if not in the view
     double *es = nullptr, *mu0 = nullptr, *mu1 = nullptr, *munew = nullptr, *y = nullptr, *efind = nullptr,
@@ -131,6 +135,8 @@ struct mpmc_hip_ctx {
     std::vector<int> dirty_atoms;   // atoms moved by update_atoms() since the last energy()
     bool all_dirty = true;
     int opt_incremental = 1, opt_overlap = 1, opt_symmetric = 1, opt_persistent_gs = 1;
+    int opt_pair_coef = 1;  // Jacobi/Palmo sweeps on pair coefficients (0: on the expanded A matrix)
+    bool box_ortho = false; // every off-diagonal basis entry is exactly zero
     int num_cus = 256;
     int opt_timing = 1;    // 0: no events, 1: sweep kernels + total only, 2: every kernel class
     int opt_sym_mode = 0;  // bit 0: alternate sweep direction, bit 1: default-policy loads
@@ -254,6 +260,10 @@ extern "C" int mpmc_hip_set_option(mpmc_hip_ctx *c, const char *name, int value)
         c->opt_sym_mode = value;
     else if (!strcmp(name, "persistent_gs"))
         c->opt_persistent_gs = value;
+    else if (!strcmp(name, "pair_coefficients")) {
+        c->opt_pair_coef = value;
+        c->all_dirty = true;
+    }
     else
         return fail("MPMC_HIP: set_option: unknown option '%s'", name);
     return 0;
@@ -337,6 +347,10 @@ extern "C" int mpmc_hip_create(mpmc_hip_ctx **out, int device, int max_atoms) {
         DALLOC(v.rrms, np, double);
         DALLOC(v.ypart, 3 * np, double);
         DALLOC(v.gsflags, 2 + np / 64 + 2, unsigned);
+        // slots past the last tile of a view are never written by the tiled sweep: keep them defined
+        for (double *p : {v.mu0, v.mu1, v.munew, v.y, v.efind, v.efchg, v.es})
+            HIPCHK(hipMemsetAsync(p, 0, 3 * np * sizeof(double), c->stream));
+        HIPCHK(hipMemsetAsync(v.rrms, 0, np * sizeof(double), c->stream));
     }
     const size_t ntile = np / 64;
     DALLOC(c->d_pairpart, ntile * ntile * kPairChannels, double);
@@ -376,7 +390,7 @@ extern "C" void mpmc_hip_destroy(mpmc_hip_ctx *c) {
     for (void *p : dptrs)
         if (p) hipFree(p);
     for (SweepView &v : c->view) {
-        void *vp[] = {v.Srow, v.ypart, v.gsflags, v.d_idx, v.d_slot, v.px, v.py, v.pz, v.palpha, v.pflags, v.A,    v.es,
+        void *vp[] = {v.Srow, v.ypart, v.gsflags, v.d_idx, v.d_slot, v.px, v.py, v.pz, v.palpha, v.pflags, v.A,    v.C, v.es,
                       v.mu0,   v.mu1, v.munew, v.y, v.efind, v.efchg, v.rrms};
         for (void *p : vp)
             if (p) hipFree(p);
@@ -467,6 +481,8 @@ extern "C" int mpmc_hip_set_box(mpmc_hip_ctx *c, const double basis[9], double p
     c->cutoff = cutoff;
     c->volume = vol;
     c->have_box = true;
+    c->box_ortho = (b[0][1] == 0.0 && b[0][2] == 0.0 && b[1][0] == 0.0 && b[1][2] == 0.0 && b[2][0] == 0.0 &&
+                    b[2][1] == 0.0);
     c->kvecf_valid = false;
     c->kvec_valid = false;
     c->lrc_valid = false;
@@ -546,6 +562,7 @@ extern "C" int mpmc_hip_upload(mpmc_hip_ctx *c, int n, const double *x, const do
     c->all_dirty = true;
     c->dirty_atoms.clear();
     c->view[0].A_valid = c->view[1].A_valid = false;
+    c->view[0].C_valid = c->view[1].C_valid = false;
     if (v0.nv > 0) HIPCHK(hipMemcpy(v0.d_idx, v0.h_idx.data(), v0.nv * sizeof(int), hipMemcpyHostToDevice));
     return 0;
 }
@@ -721,6 +738,34 @@ static int ensure_sym_scratch(SweepView &v) {
     return 0;
 }
 
+// partial-sum buffers of the tiled coefficient sweep: Srow[nt][192 nt], Zcol[nt][192 nt]
+static int ensure_coef_scratch(SweepView &v, int nt) {
+    const size_t ncol = 3 * (size_t)kCoefTile * nt;
+    const size_t need = 2 * ncol * nt;
+    if (v.symcap < need) {
+        if (v.Srow) hipFree(v.Srow);
+        v.Srow = v.Zcol = nullptr;
+        v.symcap = 0;
+        HIPCHK(hipMalloc((void **)&v.Srow, need * sizeof(double)));
+        v.symcap = need;
+    }
+    v.Zcol = v.Srow + ncol * nt;
+    return 0;
+}
+
+static int ensure_view_coef(SweepView &v, int nt) {
+    const size_t need = (size_t)nt * nt * kCoefTile * kCoefTile;
+    if (v.Ccap < need) {
+        if (v.C) hipFree(v.C);
+        v.C = nullptr;
+        v.Ccap = 0;
+        HIPCHK(hipMalloc((void **)&v.C, need * sizeof(double2)));
+        v.Ccap = need;
+        v.C_valid = false;
+    }
+    return 0;
+}
+
 static int ensure_view_matrix(SweepView &v) {
     const size_t need = (size_t)(3 * (size_t)v.nvpad) * (3 * (size_t)v.nvpad);
     if (v.Acap < need) {
@@ -845,7 +890,7 @@ extern "C" int mpmc_hip_energy(mpmc_hip_ctx *c, mpmc_hip_result *out) {
             HIPCHK(hipMemsetAsync(c->d_res + R_UPOL, 0, 2 * sizeof(double), c->stream));
         }
         // the resident A only tracks moves while it is being maintained
-        if (!do_polar || P.polar_zodid) c->view[0].A_valid = false;
+        if (!do_polar || P.polar_zodid) c->view[0].A_valid = c->view[0].C_valid = false;
         }
     }
     if (c->opt_overlap) hipStreamWaitEvent(c->stream, c->ev_join, 0);

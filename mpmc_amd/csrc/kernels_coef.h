@@ -1,0 +1,335 @@
+// kernels_coef.h -- dipole sweep on PAIR COEFFICIENTS instead of the expanded A matrix.
+//
+// Every off-diagonal 3x3 block of the reference's A matrix (src/polarization/thole_matrix.c:72-137)
+// has the form
+//     T_ij = c3 I - 3 c5 d d^T,    c3 = damp1(r)/r^3,  c5 = damp2(r)/r^5,  d = minimum-image r_i - r_j,
+// i.e. nine stored doubles carry two numbers that are expensive to produce (exp, divide, sqrt) and
+// three that are cheap (d: a dozen fp64 operations from the coordinates).  The sweep is HBM-bound on
+// the matrix read, so the solver keeps only {c3, c5} per pair -- 16 B instead of 72 B -- and the
+// sweep rebuilds d on the fly:  E_i -= sum_j [ c3 mu_j - 3 c5 (d . mu_j) d ].  T is symmetric in
+// (i, j), so each pair is visited once and feeds both its row and its column (as symv_kernel does).
+// The lattice translation is chosen by exactly the arithmetic of minimum_image() (same rint()
+// argument bits), so a pair on a half-box tie uses the image its coefficients were built with.
+//
+// Storage: 64 x 64-pair tiles (ti <= tj), "rotated" so that the access of the sweep is coalesced:
+//     element (l, s) of tile (ti, tj) is the pair  i = 64 ti + l,  j = 64 tj + ((l + s) & 63)
+//     C[((ti * nt + tj) * 64 + s) * 64 + l] = {c3, c5}            (nt = ceil(nv / 64))
+// At step s lane l of a wave works on row atom l and column atom (l + s) & 63: the row sums stay in
+// the lane, the column sums travel one lane per step (DPP wave_rol:1), the column atoms' coordinates
+// and dipoles are read from LDS at a rotating, conflict-free index.  A diagonal tile holds every
+// ordered pair of its 64 atoms (s = 0 is the self pair, stored as zero) and feeds rows only.
+// Pairs with an invalid (padding) partner are stored as zero, so no masking happens in the sweep.
+#pragma once
+#include "device_common.h"
+#include "kernels_polar.h"
+
+namespace mpmc {
+
+constexpr int kCoefTile = 64;        // atoms per tile edge (= one wave)
+constexpr int kCoefWaves = 4;        // waves per sweep workgroup; each takes 64/4 = 16 steps of a tile
+constexpr int kCoefSteps = kCoefTile / kCoefWaves;
+
+// Displacement of the minimum image.  The lattice translation comes from the same un-contracted
+// arithmetic as minimum_image() (bit-identical rint() arguments => identical image, also on ties);
+// the subtraction of the translation may use FMAs (the result differs from minimum_image()'s by at
+// most an ulp, which only perturbs d, not the choice of image).
+template <int ORTHO>
+__device__ __forceinline__ void image_displacement(const DevBox &bx, double dx, double dy, double dz, double &ox,
+                                                   double &oy, double &oz) {
+    double i0, i1, i2;
+    {
+#pragma clang fp contract(off)
+        if (ORTHO) {
+            // off-diagonal basis entries are exactly zero: their products are +-0 and drop out bit-exactly
+            i0 = bx.rb[0][0] * dx;
+            i1 = bx.rb[1][1] * dy;
+            i2 = bx.rb[2][2] * dz;
+        } else {
+            i0 = bx.rb[0][0] * dx;
+            i0 = i0 + bx.rb[1][0] * dy;
+            i0 = i0 + bx.rb[2][0] * dz;
+            i1 = bx.rb[0][1] * dx;
+            i1 = i1 + bx.rb[1][1] * dy;
+            i1 = i1 + bx.rb[2][1] * dz;
+            i2 = bx.rb[0][2] * dx;
+            i2 = i2 + bx.rb[1][2] * dy;
+            i2 = i2 + bx.rb[2][2] * dz;
+        }
+    }
+    i0 = rint(i0);
+    i1 = rint(i1);
+    i2 = rint(i2);
+    if (ORTHO) {
+        ox = fma(-bx.b[0][0], i0, dx);
+        oy = fma(-bx.b[1][1], i1, dy);
+        oz = fma(-bx.b[2][2], i2, dz);
+    } else {
+        ox = fma(-bx.b[2][0], i2, fma(-bx.b[1][0], i1, fma(-bx.b[0][0], i0, dx)));
+        oy = fma(-bx.b[2][1], i2, fma(-bx.b[1][1], i1, fma(-bx.b[0][1], i0, dy)));
+        oz = fma(-bx.b[2][2], i2, fma(-bx.b[1][2], i1, fma(-bx.b[0][2], i0, dz)));
+    }
+}
+
+// 64-lane rotation by one: lane l receives the value of lane (l + 1) & 63 (two v_mov_b32_dpp wave_rol:1)
+__device__ __forceinline__ double wave_rotate_down(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x134, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x134, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double2 stream_load_coef(const double2 *p) {
+    const native_double2 v = __builtin_nontemporal_load(reinterpret_cast<const native_double2 *>(p));
+    return make_double2(v.x, v.y);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Full build of the coefficient tiles (upload, volume change, insert/delete).
+// grid = (nt [tj], nt [ti]); block = 256 (wave w fills steps 16 w .. 16 w + 15); tiles below the
+// diagonal exit.  `a` is the view's atom set (coordinates / flags in slot order).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * kCoefWaves) void build_coef_kernel(DevAtoms a, DevBox bx, double damp, int nt,
+                                                                       double2 *__restrict__ C) {
+    const int tj = blockIdx.x, ti = blockIdx.y;
+    if (tj < ti) return;
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __shared__ double sx[64], sy[64], sz[64];
+    __shared__ int sv[64];
+    if (w == 0) {
+        sx[l] = a.x[64 * tj + l];
+        sy[l] = a.y[64 * tj + l];
+        sz[l] = a.z[64 * tj + l];
+        sv[l] = a.flags[64 * tj + l] & kValid;
+    }
+    const double xi = a.x[64 * ti + l], yi = a.y[64 * ti + l], zi = a.z[64 * ti + l];
+    const bool vi = a.flags[64 * ti + l] & kValid;
+    __syncthreads();
+    double2 *tile = C + (size_t)(ti * nt + tj) * (kCoefTile * kCoefTile);
+    for (int s = kCoefSteps * w; s < kCoefSteps * (w + 1); ++s) {
+        const int jj = (l + s) & 63;
+        double c3 = 0.0, c5 = 0.0, dx, dy, dz;
+        if (vi && sv[jj] && !(ti == tj && s == 0))
+            thole_coef(bx, damp, xi - sx[jj], yi - sy[jj], zi - sz[jj], c3, c5, dx, dy, dz);
+        tile[s * 64 + l] = make_double2(c3, c5);
+    }
+}
+
+// Incremental update after an MC move: the coefficients of every pair that involves a moved atom.
+// grid = (nt, ndirty); block = 64: thread = partner k of dirty slot a.  A pair of two moved atoms is
+// written by both (same value).  Same function of the same coordinates as the full build, hence
+// bit-identical to it.
+__global__ __launch_bounds__(64) void update_coef_kernel(DevAtoms a, DevBox bx, double damp, DirtyList dirty, int nt,
+                                                          double2 *__restrict__ C) {
+    const int sa = dirty.slot[blockIdx.y];
+    const int k = blockIdx.x * 64 + threadIdx.x;
+    if (k == sa) return;
+    const int ta = sa >> 6, la = sa & 63, tk = k >> 6, lk = k & 63;
+    // the build evaluates element (i, j) from r_i - r_j with i the row atom: keep that orientation
+    // (c3, c5 depend on |d| only and the minimum image is odd in d, so either gives the same bits)
+    const bool a_is_row = (ta < tk) || (ta == tk);
+    const int i = a_is_row ? sa : k, j = a_is_row ? k : sa;
+    double c3 = 0.0, c5 = 0.0, dx, dy, dz;
+    if ((a.flags[i] & kValid) && (a.flags[j] & kValid))
+        thole_coef(bx, damp, a.x[i] - a.x[j], a.y[i] - a.y[j], a.z[i] - a.z[j], c3, c5, dx, dy, dz);
+    const double2 v = make_double2(c3, c5);
+    const size_t tsz = kCoefTile * kCoefTile;
+    if (ta < tk) {
+        C[(size_t)(ta * nt + tk) * tsz + ((lk - la) & 63) * 64 + la] = v;
+    } else if (ta > tk) {
+        C[(size_t)(tk * nt + ta) * tsz + ((la - lk) & 63) * 64 + lk] = v;
+    } else {
+        double2 *tile = C + (size_t)(ta * nt + ta) * tsz;
+        tile[((lk - la) & 63) * 64 + la] = v;
+        tile[((la - lk) & 63) * 64 + lk] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The sweep.  grid = nt (nt + 1) / 2 workgroups, one per tile of the upper triangle (long rows
+// first); block = 256: wave w takes steps 16 w .. 16 w + 15, its 16 coefficient loads (16 B per
+// lane each, 1 KiB per wave-instruction, non-temporal) are issued up front.  The four quarters are
+// combined through LDS; the tile's row sums go to Srow[tj][192 ti + 64 p + l], its column sums to
+// Zcol[ti][192 tj + 64 p + l] (p = component; planar inside a 64-atom block so that stores and the
+// finish kernel's loads are coalesced).  Everything is summed in a fixed order => deterministic.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void upper_tile_of(int t, int nt, int &ti, int &tj) {
+    // rows ti = 0, 1, ... hold nt, nt - 1, ... tiles; first tile of row ti is t0(ti) = ti nt - ti (ti - 1) / 2
+    const float b = 2.0f * (float)nt + 1.0f;
+    int r = (int)((b - sqrtf(b * b - 8.0f * (float)t)) * 0.5f);
+    r = max(0, min(r, nt - 1));
+    while (r > 0 && r * nt - r * (r - 1) / 2 > t) --r;
+    while ((r + 1) * nt - (r + 1) * r / 2 <= t) ++r;
+    ti = r;
+    tj = r + (t - (r * nt - r * (r - 1) / 2));
+}
+
+template <int ORTHO>
+__global__ __launch_bounds__(64 * kCoefWaves) void pair_sweep_kernel(const double2 *__restrict__ C, int nt,
+                                                                       const double *__restrict__ x,
+                                                                       const double *__restrict__ y,
+                                                                       const double *__restrict__ z,
+                                                                       const double *__restrict__ mu, DevBox bx,
+                                                                       double *__restrict__ Srow,
+                                                                       double *__restrict__ Zcol) {
+    int ti, tj;
+    upper_tile_of(blockIdx.x, nt, ti, tj);
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const bool diag = (ti == tj);
+    __shared__ double2 jxy[64], jzm[64], jmm[64];  // {x, y}, {z, mu_x}, {mu_y, mu_z} of the column atoms
+    __shared__ double red[kCoefWaves][6][64];
+    if (w == 0) {
+        const int j = 64 * tj + l;
+        jxy[l] = make_double2(x[j], y[j]);
+        jzm[l] = make_double2(z[j], mu[3 * j]);
+        jmm[l] = make_double2(mu[3 * j + 1], mu[3 * j + 2]);
+    }
+    const int i = 64 * ti + l;
+    const double xi = x[i], yi = y[i], zi = z[i];
+    const double mix = mu[3 * i], miy = mu[3 * i + 1], miz = mu[3 * i + 2];
+    const double2 *tile = C + (size_t)(ti * nt + tj) * (kCoefTile * kCoefTile) + (size_t)(kCoefSteps * w) * 64 + l;
+    double2 c[kCoefSteps];
+#pragma unroll
+    for (int k = 0; k < kCoefSteps; ++k) c[k] = stream_load_coef(tile + 64 * k);
+    __syncthreads();
+    double sx = 0.0, sy = 0.0, sz = 0.0, zx = 0.0, zy = 0.0, zz = 0.0;
+#pragma unroll
+    for (int k = 0; k < kCoefSteps; ++k) {
+        const int jj = (l + kCoefSteps * w + k) & 63;
+        const double2 pa = jxy[jj], pb = jzm[jj], pm = jmm[jj];
+        double dx, dy, dz;
+        image_displacement<ORTHO>(bx, xi - pa.x, yi - pa.y, zi - pb.x, dx, dy, dz);
+        const double c3 = c[k].x, c5m = -3.0 * c[k].y;
+        // row: T mu_j = c3 mu_j - 3 c5 (d . mu_j) d
+        const double wj = c5m * fma(dz, pm.y, fma(dy, pm.x, dx * pb.y));
+        sx = fma(wj, dx, fma(c3, pb.y, sx));
+        sy = fma(wj, dy, fma(c3, pm.x, sy));
+        sz = fma(wj, dz, fma(c3, pm.y, sz));
+        // column: the running sums follow their column atom to the next lane
+        if (k > 0) {
+            zx = wave_rotate_down(zx);
+            zy = wave_rotate_down(zy);
+            zz = wave_rotate_down(zz);
+        }
+        const double wi = c5m * fma(dz, miz, fma(dy, miy, dx * mix));
+        zx = fma(wi, dx, fma(c3, mix, zx));
+        zy = fma(wi, dy, fma(c3, miy, zy));
+        zz = fma(wi, dz, fma(c3, miz, zz));
+    }
+    red[w][0][l] = sx;
+    red[w][1][l] = sy;
+    red[w][2][l] = sz;
+    const int jl = (l + kCoefSteps * w + kCoefSteps - 1) & 63;  // column atom this lane ended on
+    red[w][3][jl] = zx;
+    red[w][4][jl] = zy;
+    red[w][5][jl] = zz;
+    __syncthreads();
+    const size_t ncol = 3 * (size_t)kCoefTile * nt;
+    if (w < 3) {
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < kCoefWaves; ++q) s += red[q][w][l];
+        Srow[(size_t)tj * ncol + 192 * ti + 64 * w + l] = s;
+    } else if (!diag) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            double s = 0.0;
+#pragma unroll
+            for (int q = 0; q < kCoefWaves; ++q) s += red[q][3 + p][l];
+            Zcol[(size_t)ti * ncol + 192 * tj + 64 * p + l] = s;
+        }
+    }
+}
+
+// y_i = sum_{tj >= t} Srow[tj][block t] + sum_{ti < t} Zcol[ti][block t]  (t = i / 64; nt terms, fixed
+// order), then the sweep epilogue of sweep_kernel (new mu, SOR/ESOR mix, RRMS, max-change | Palmo).
+// grid = nt; block = 1024 = 64 atoms x 16 term groups, combined through LDS.
+constexpr int kCoefFinishGroups = 16;
+template <int MODE>
+__global__ __launch_bounds__(1024) void pair_finish_kernel(int nt, const double *__restrict__ Srow,
+                                                            const double *__restrict__ Zcol,
+                                                            const double *__restrict__ alpha,
+                                                            const int *__restrict__ flags,
+                                                            const double *__restrict__ mu_in,
+                                                            const double *__restrict__ es,
+                                                            double *__restrict__ ef_induced, double *__restrict__ out,
+                                                            double *__restrict__ rrms,
+                                                            unsigned long long *__restrict__ errmax, SweepParams sp) {
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int t = blockIdx.x;
+    const int i = 64 * t + lane;
+    const size_t ncol = 3 * (size_t)kCoefTile * nt;
+    __shared__ double part[kCoefFinishGroups][3][64];
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    // four terms per trip, loads issued together (a term's address does not depend on data)
+    for (int u0 = g; u0 < nt; u0 += 4 * kCoefFinishGroups) {
+        double v[4][3];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int u = u0 + k * kCoefFinishGroups;
+            const bool on = u < nt;
+            const int uu = on ? u : g;
+            // u < nt - t: row partial of tile (t, t + u); otherwise column partial of tile (u - (nt - t), t)
+            const double *p = (uu < nt - t) ? Srow + (size_t)(t + uu) * ncol : Zcol + (size_t)(uu - (nt - t)) * ncol;
+            p += 192 * t + lane;
+            v[k][0] = on ? p[0] : 0.0;
+            v[k][1] = on ? p[64] : 0.0;
+            v[k][2] = on ? p[128] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            s0 += v[k][0];
+            s1 += v[k][1];
+            s2 += v[k][2];
+        }
+    }
+    part[g][0][lane] = s0;
+    part[g][1][lane] = s1;
+    part[g][2][lane] = s2;
+    __syncthreads();
+    if (g != 0) return;
+    double s[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < kCoefFinishGroups; ++k) acc += part[k][p][lane];
+        s[p] = acc;
+    }
+    const double al = alpha[i];
+    const bool valid = flags[i] & kValid;
+    if ((MODE == kSweepJacobi && (al == 0.0 || !valid)) || (MODE == kSweepPalmo && !valid)) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            out[3 * i + p] = 0.0;
+            if (MODE == kSweepJacobi) ef_induced[3 * i + p] = 0.0;
+        }
+        if (MODE == kSweepJacobi && sp.want_rrms) rrms[i] = 0.0;
+        return;
+    }
+    if (MODE == kSweepJacobi) {
+        double d2 = 0.0, n2 = 0.0, emax = 0.0;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const double e = -s[p];
+            const double old = mu_in[3 * i + p];
+            const double nw = al * (es[3 * i + p] + e);
+            ef_induced[3 * i + p] = e;
+            out[3 * i + p] = sp.w_new * nw + sp.w_old * old;
+            const double d = nw - old;
+            d2 += d * d;
+            n2 += nw * nw;
+            emax = fmax(emax, d * d);
+        }
+        if (sp.want_rrms) {
+            double rr = sqrt(d2 / n2);  // calc_dipole_rrms, thole_iterative.c:61-77
+            if (!isfinite(rr)) rr = 0.0;
+            rrms[i] = rr;
+        }
+        atomicMax(errmax + sp.err_slot, (unsigned long long)__double_as_longlong(emax));
+    } else {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) out[3 * i + p] = -ef_induced[3 * i + p] - s[p];
+    }
+}
+
+}  // namespace mpmc

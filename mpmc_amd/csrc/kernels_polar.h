@@ -209,10 +209,11 @@ __global__ __launch_bounds__(64) void field_reduce_kernel(const double *__restri
 // ---------------------------------------------------------------------------------------------
 constexpr int kARows = 16;
 
-__device__ __forceinline__ void thole_tensor(const DevBox &bx, double damp, double dx0, double dy0, double dz0,
-                                             double &xx, double &xy, double &xz, double &yy, double &yz,
-                                             double &zz) {
-    double r, rimg, dx, dy, dz;
+// Radial coefficients of the damped dipole tensor T = c3 I - 3 c5 d d^T (thole_matrix.c:72-137) and the
+// minimum-image displacement d they belong to.
+__device__ __forceinline__ void thole_coef(const DevBox &bx, double damp, double dx0, double dy0, double dz0,
+                                           double &c3, double &c5, double &dx, double &dy, double &dz) {
+    double r, rimg;
     minimum_image(bx, dx0, dy0, dz0, r, rimg, dx, dy, dz);
     double ir3, ir5;
     if (rimg == 0.0) {
@@ -227,7 +228,15 @@ __device__ __forceinline__ void thole_tensor(const DevBox &bx, double damp, doub
     const double explr = exp(-l * rimg);
     const double damp1 = 1.0 - explr * (0.5 * l2 * r2 + l * rimg + 1.0);
     const double damp2 = damp1 - explr * (l3 * r2 * rimg / 6.0);
-    const double c5 = damp2 * ir5, c3 = damp1 * ir3;
+    c5 = damp2 * ir5;
+    c3 = damp1 * ir3;
+}
+
+__device__ __forceinline__ void thole_tensor(const DevBox &bx, double damp, double dx0, double dy0, double dz0,
+                                             double &xx, double &xy, double &xz, double &yy, double &yz,
+                                             double &zz) {
+    double c3, c5, dx, dy, dz;
+    thole_coef(bx, damp, dx0, dy0, dz0, c3, c5, dx, dy, dz);
     xx = -3.0 * dx * dx * c5 + c3;
     xy = -3.0 * dx * dy * c5;
     xz = -3.0 * dx * dz * c5;
