@@ -24,6 +24,16 @@ constexpr int kWave = 64;
 
 enum AtomFlag : int { kFrozen = 1, kValid = 2 };
 
+// 64-atom blocks (atom order) that hold an atom moved since the last energy(); carried in the kernel
+// arguments.  n == 0 means "everything": the tiled pair/field kernels then cover their whole grid,
+// otherwise only the tiles that touch one of these blocks (their partial sums persist in HBM, and a
+// tile's partial is a function of its two blocks' atoms only, so the result is bit-identical).
+constexpr int kMaxDirtyBlocks = 16;
+struct DirtyBlocks {
+    int n;
+    int blk[kMaxDirtyBlocks];
+};
+
 // Periodic cell, passed by value (lands in SGPRs / kernarg).
 struct DevBox {
     double b[3][3];   // basis, rows = lattice vectors

@@ -136,6 +136,12 @@ struct mpmc_hip_ctx {
     bool all_dirty = true;
     int opt_incremental = 1, opt_overlap = 1, opt_symmetric = 1, opt_persistent_gs = 1;
     int opt_pair_coef = 1;  // Jacobi/Palmo sweeps on pair coefficients (0: on the expanded A matrix)
+    int opt_incremental_pairs = 1;  // LJ/Ewald-real and static-field tile partials persist between calls
+    bool pair_part_valid = false;   // d_pairpart holds the tile partials of the configuration before the pending moves
+    bool field_part_valid = false;  // same for d_fieldpart (real-space static field)
+    int field_key = -1;             // mode / chunking the resident field partials were made with
+    double *d_lrcpart = nullptr;    // scratch of the (cached) long-range correction
+    DirtyBlocks dirty_blocks;       // of the energy() call in progress
     bool box_ortho = false; // every off-diagonal basis entry is exactly zero
     int num_cus = 256;
     int opt_timing = 1;    // 0: no events, 1: sweep kernels + total only, 2: every kernel class
@@ -263,6 +269,9 @@ extern "C" int mpmc_hip_set_option(mpmc_hip_ctx *c, const char *name, int value)
     else if (!strcmp(name, "pair_coefficients")) {
         c->opt_pair_coef = value;
         c->all_dirty = true;
+    } else if (!strcmp(name, "incremental_pairs")) {
+        c->opt_incremental_pairs = value;
+        c->all_dirty = true;
     }
     else
         return fail("MPMC_HIP: set_option: unknown option '%s'", name);
@@ -354,6 +363,7 @@ extern "C" int mpmc_hip_create(mpmc_hip_ctx **out, int device, int max_atoms) {
     }
     const size_t ntile = np / 64;
     DALLOC(c->d_pairpart, ntile * ntile * kPairChannels, double);
+    DALLOC(c->d_lrcpart, ntile * ntile, double);
     const size_t nchunk_max = std::max<size_t>(1, np / 64) + 16;  // + k-chunk slots of the Ewald field
     DALLOC(c->d_fieldpart, nchunk_max * 3 * np, double);
     DALLOC(c->d_res, R_COUNT, double);
@@ -386,7 +396,7 @@ extern "C" void mpmc_hip_destroy(mpmc_hip_ctx *c) {
     void *dptrs[] = {c->d_x,   c->d_y,     c->d_z,     c->d_q,    c->d_alpha, c->d_eps,      c->d_sig,
                      c->d_molmass, c->d_mol, c->d_flags, c->d_es, c->d_mu,    c->d_efind,    c->d_efchg,
                      c->d_tmp3, c->d_rank, c->d_errmax, c->d_pairpart, c->d_fieldpart, c->d_perk, c->d_kvec,
-                     c->d_res,  c->d_kvecf, c->d_sf};
+                     c->d_res,  c->d_kvecf, c->d_sf, c->d_lrcpart};
     for (void *p : dptrs)
         if (p) hipFree(p);
     for (SweepView &v : c->view) {
@@ -432,6 +442,7 @@ extern "C" int mpmc_hip_set_params(mpmc_hip_ctx *c, const mpmc_hip_params *p) {
         if (p->polar_gamma < 0.0) return fail("MPMC_HIP: invalid Pre-cond/SOR/ESOR gamma set");
     }
     if (p->polar_damp != c->par.polar_damp) c->all_dirty = true;
+    c->pair_part_valid = c->field_part_valid = false;
     c->par = *p;
     c->have_params = true;
     c->kvecf_valid = false;
@@ -813,6 +824,27 @@ extern "C" int mpmc_hip_energy(mpmc_hip_ctx *c, mpmc_hip_result *out) {
     const DevBox bx = dev_box(c);
     const int ntile = c->npad / 64;
     int polar_iterations = 0, iter_success = 0;
+    // 64-atom blocks touched by the moves since the last call (n = 0: recompute every tile)
+    DirtyBlocks dirty_blocks;
+    dirty_blocks.n = 0;
+    if (c->all_dirty || !c->opt_incremental_pairs) {
+        c->pair_part_valid = c->field_part_valid = false;
+    } else {
+        for (int atom : c->dirty_atoms) {
+            const int b = atom / 64;
+            bool seen = false;
+            for (int k = 0; k < dirty_blocks.n; ++k) seen |= (dirty_blocks.blk[k] == b);
+            if (seen) continue;
+            if (dirty_blocks.n == kMaxDirtyBlocks) {
+                c->pair_part_valid = c->field_part_valid = false;
+                dirty_blocks.n = 0;
+                break;
+            }
+            dirty_blocks.blk[dirty_blocks.n++] = b;
+        }
+    }
+    for (int k = dirty_blocks.n; k < kMaxDirtyBlocks; ++k) dirty_blocks.blk[k] = 0;
+    c->dirty_blocks = dirty_blocks;
 
     // ---- fork: LJ / Ewald kernels (fp64-VALU bound) run on stream2 while the polarization chain
     // (HBM bound) runs on the main stream -- the device-side analogue of the reference starting its
@@ -836,8 +868,8 @@ extern "C" int mpmc_hip_energy(mpmc_hip_ctx *c, mpmc_hip_result *out) {
         if (P.rd_lrc) {
             if (!c->lrc_valid) {
                 ScopedTimer t(c, T_OTHER, sb);
-                hipLaunchKernelGGL(lj_lrc_kernel, dim3(ntile, ntile), dim3(64), 0, sb, a, bx, c->d_pairpart);
-                hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, sb, c->d_pairpart, ntile * ntile, 1,
+                hipLaunchKernelGGL(lj_lrc_kernel, dim3(ntile, ntile), dim3(64), 0, sb, a, bx, c->d_lrcpart);
+                hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, sb, c->d_lrcpart, ntile * ntile, 1,
                                    c->d_res + R_LRC);
                 c->lrc_valid = true;
             }
@@ -856,13 +888,19 @@ extern "C" int mpmc_hip_energy(mpmc_hip_ctx *c, mpmc_hip_result *out) {
             pp.fh_order = P.feynman_hibbs ? P.feynman_hibbs_order : 0;
             pp.wolf = P.wolf;
             pp.erfaRoverR = std::erf(c->ewald_alpha * c->cutoff) / c->cutoff;
-            const dim3 grid(ntile, ntile), block(64);
-            if (pp.fh_order == 0)
-                hipLaunchKernelGGL(pair_rd_es_kernel<0>, grid, block, 0, sb, a, bx, pp, c->d_pairpart);
+            // tile partials persist: after a single-molecule move only the tiles of the moved atoms' blocks
+            DirtyBlocks sel = dirty_blocks;
+            if (!c->pair_part_valid) sel.n = 0;
+            const dim3 grid(ntile, sel.n > 0 ? sel.n : ntile), block(64);
+            if (c->pair_part_valid && c->dirty_atoms.empty())
+                ;  // nothing moved since the partials were made
+            else if (pp.fh_order == 0)
+                hipLaunchKernelGGL(pair_rd_es_kernel<0>, grid, block, 0, sb, a, bx, pp, sel, c->d_pairpart);
             else if (pp.fh_order == 2)
-                hipLaunchKernelGGL(pair_rd_es_kernel<2>, grid, block, 0, sb, a, bx, pp, c->d_pairpart);
+                hipLaunchKernelGGL(pair_rd_es_kernel<2>, grid, block, 0, sb, a, bx, pp, sel, c->d_pairpart);
             else
-                hipLaunchKernelGGL(pair_rd_es_kernel<4>, grid, block, 0, sb, a, bx, pp, c->d_pairpart);
+                hipLaunchKernelGGL(pair_rd_es_kernel<4>, grid, block, 0, sb, a, bx, pp, sel, c->d_pairpart);
+            c->pair_part_valid = true;
             hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, sb, c->d_pairpart, ntile * ntile,
                                kPairChannels, c->d_res + R_RD_PAIR);
         }

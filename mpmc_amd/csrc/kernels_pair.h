@@ -45,12 +45,23 @@ __device__ __forceinline__ void load_jtile(JTile &t, const DevAtoms &a, int j0, 
     t.flags[lane] = a.flags[j];
 }
 
-// grid = (npad/64 [J], npad/64 [I]); block = 64 threads.  Tiles with J < I exit.
+// Full pass: grid = (npad/64 [J], npad/64 [I]); block = 64 threads; tiles with J < I only clear their slot.
+// Incremental pass (sel.n > 0): grid = (npad/64, sel.n): block (x, y) recomputes the tile of blocks
+// {sel.blk[y], x}, lower block as the row tile as in the full pass; every other tile keeps its partial
+// from the previous call (the reference keeps per-pair energies and recalculates only the pairs an MC
+// move touched, pairs.c:238-249 / lj.c:182; here the cached unit is a 64 x 64 tile).
 template <int FH>
-__global__ __launch_bounds__(64) void pair_rd_es_kernel(DevAtoms a, DevBox bx, PairParams pp,
+__global__ __launch_bounds__(64) void pair_rd_es_kernel(DevAtoms a, DevBox bx, PairParams pp, DirtyBlocks sel,
                                                          double *__restrict__ partials) {
-    const int I = blockIdx.y, J = blockIdx.x;
+    int I = blockIdx.y, J = blockIdx.x;
     const int lane = threadIdx.x;
+    if (sel.n > 0) {
+        const int d = sel.blk[blockIdx.y], o = blockIdx.x;
+        for (int k = 0; k < (int)blockIdx.y; ++k)
+            if (sel.blk[k] == o) return;  // the tile of two dirty blocks belongs to the earlier one
+        I = min(d, o);
+        J = max(d, o);
+    }
     double *out = partials + (size_t)(I * gridDim.x + J) * kPairChannels;
     if (J < I) {
         if (lane < kPairChannels) out[lane] = 0.0;

@@ -30,12 +30,27 @@ struct FieldParams {
     int chunk;          // j atoms per block (multiple of 64)
 };
 
+// Incremental pass (sel.n > 0): grid = (max(nchunk, npad/64), sel.n, 2); z = 0 recomputes the partials of
+// the dirty block's atoms against every chunk, z = 1 those of every atom against the dirty block's chunk.
+// All other partials persist from the previous call (same values a full pass would write).
 template <int MODE>
-__global__ __launch_bounds__(64) void static_field_kernel(DevAtoms a, DevBox bx, FieldParams fp,
+__global__ __launch_bounds__(64) void static_field_kernel(DevAtoms a, DevBox bx, FieldParams fp, DirtyBlocks sel,
                                                            double *__restrict__ part) {
     const int lane = threadIdx.x;
-    const int i = blockIdx.y * kWave + lane;
-    const int jbeg = blockIdx.x * fp.chunk;
+    int tile = blockIdx.y, chunk = blockIdx.x;
+    if (sel.n > 0) {
+        const int d = sel.blk[blockIdx.y];
+        if (blockIdx.z == 0) {
+            tile = d;
+            if (chunk * fp.chunk >= a.npad) return;
+        } else {
+            tile = blockIdx.x;
+            chunk = (d * kWave) / fp.chunk;
+            if (tile * kWave >= a.npad) return;
+        }
+    }
+    const int i = tile * kWave + lane;
+    const int jbeg = chunk * fp.chunk;
     __shared__ double sx[kWave], sy[kWave], sz[kWave], sq[kWave];
     __shared__ float fx[kWave], fy[kWave], fz[kWave];  // fp32 copies for the screening pass
     __shared__ int smol[kWave], sfl[kWave];
@@ -115,7 +130,7 @@ __global__ __launch_bounds__(64) void static_field_kernel(DevAtoms a, DevBox bx,
             }
         }
     }
-    const size_t base = (size_t)blockIdx.x * 3 * a.npad;
+    const size_t base = (size_t)chunk * 3 * a.npad;
     part[base + i] = ex;
     part[base + a.npad + i] = ey;
     part[base + 2 * (size_t)a.npad + i] = ez;

@@ -257,10 +257,13 @@ def test_frozen_framework_and_update_atoms():
     eng.close()
 
 
-def test_incremental_amatrix_is_bit_identical_to_full_rebuild():
-    """A stays resident between steps and only the moved atoms' rows/columns are rewritten
-    (O(N m) instead of the reference's O(N^2) rebuild).  A chain of accepted and rejected moves must
-    give bitwise the same energies as rebuilding A from scratch every step, and match the oracle."""
+@pytest.mark.parametrize("pair_coefficients", [1, 0])
+def test_incremental_updates_are_bit_identical_to_full_recomputation(pair_coefficients):
+    """The dipole-tensor data (pair coefficients, or the expanded A matrix) and the tile partials of the
+    LJ/Ewald pair kernel and of the static field stay resident between steps; after a move only what
+    involves a moved atom is rewritten (O(N m) instead of the reference's O(N^2) per step).  A chain of
+    accepted and rejected moves must give bitwise the same energies as recomputing everything from
+    scratch every step, and match the oracle."""
     s = load("socmof_bssp_1228")
     p = dict(FX["socmof_bssp_1228"]["params"])
     p["polar_max_iter"] = 4
@@ -269,7 +272,9 @@ def test_incremental_amatrix_is_bit_identical_to_full_rebuild():
     for inc in (1, 0):
         e = engine.Engine(1228)
         e.load_system(s, p)
+        e.set_option("pair_coefficients", pair_coefficients)
         e.set_option("incremental_amatrix", inc)
+        e.set_option("incremental_pairs", inc)
         engs.append(e)
     pos = s["pos"].copy()
     hist = [[], []]
@@ -281,6 +286,8 @@ def test_incremental_amatrix_is_bit_identical_to_full_rebuild():
         for k, e in enumerate(engs):
             e.update_atoms(first, new)
             hist[k].append(e.energy())
+            if step == 4:
+                hist[k].append(e.energy())  # a second call with nothing moved in between
             if not accept:
                 e.update_atoms(first, pos[first:first + 5])
         if accept:
@@ -290,20 +297,27 @@ def test_incremental_amatrix_is_bit_identical_to_full_rebuild():
             assert a[key] == b[key], key
     s2 = dict(s)
     s2["pos"] = pos
+    want = oracle.energy(s2, p, want_vectors=True)
     for e in engs:
-        check_energies(e.energy(), oracle.energy(s2, p))
+        r = e.energy()
+        check_energies(r, want)
+        d = e.dipoles()
+        assert np.abs(d["ef_static"] - want["ef_static"]).max() <= 1e-10 * np.abs(want["ef_static"]).max()
+        assert np.abs(d["mu"] - want["mu"]).max() <= 1e-10 * np.abs(want["mu"]).max()
         e.close()
 
 
-def test_symmetric_sweep_matches_full_sweep():
-    """The default sweep reads only the upper triangle of A (each element used for both products);
-    option symmetric_sweep=0 streams the full matrix.  Same dipoles to rounding, both match the oracle."""
+def test_sweep_variants_agree():
+    """The default sweep runs on pair coefficients (c3, c5 per pair, geometry rebuilt in registers); with
+    pair_coefficients=0 it streams the expanded A matrix, either its upper triangle (each element used for
+    both products) or, with symmetric_sweep=0, all of it.  Same dipoles to rounding, all match the oracle."""
     s = load("socmof_bssp_1228")
     p = dict(FX["socmof_bssp_1228"]["params"], polar_palmo=1, polar_sor=1, polar_gamma=0.9, polar_rrms=1)
     res = []
-    for sym in (2, 0):  # 2 = force the symmetric kernel even below its size threshold
+    for coef, sym in ((1, 1), (0, 2), (0, 0)):  # 2 = force the symmetric kernel even below its size threshold
         e = engine.Engine(1228)
         e.load_system(s, p)
+        e.set_option("pair_coefficients", coef)
         e.set_option("symmetric_sweep", sym)
         r = e.energy()
         r.update(e.dipoles())
@@ -313,7 +327,11 @@ def test_symmetric_sweep_matches_full_sweep():
     for r in res:
         check_energies(r, want)
         assert np.abs(r["mu"] - want["mu"]).max() <= 1e-10 * np.abs(want["mu"]).max()
-    assert np.abs(res[0]["mu"] - res[1]["mu"]).max() <= 1e-12 * np.abs(want["mu"]).max()
+        pol = s["alpha"] != 0.0  # dE_ind is formed on polarizable sites only (see test_polarization_variants_1024)
+        assert np.abs(r["ef_induced_change"] - want["ef_induced_change"])[pol].max() <= 1e-9 * np.abs(
+            want["ef_induced"]).max()
+    for r in res[1:]:
+        assert np.abs(res[0]["mu"] - r["mu"]).max() <= 1e-12 * np.abs(want["mu"]).max()
 
 
 def test_ragged_sizes_and_padding():
@@ -426,7 +444,7 @@ def test_16384_atoms_polarizable_invariances():
     fresh.load_system(s2, p)
     e2 = fresh.energy()
     assert e2["energy"] == e1["energy"] and e2["polarization_energy"] == e1["polarization_energy"]
-    fresh.set_option("symmetric_sweep", 0)
+    fresh.set_option("pair_coefficients", 0)  # same sweep on the expanded A matrix (upper triangle)
     e3 = fresh.energy()
     assert rel(e3["polarization_energy"], e2["polarization_energy"]) < 1e-11
     eng.close()
