@@ -19,6 +19,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <ctime>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -102,8 +103,10 @@ struct SweepView {
     size_t Acap = 0;  // doubles
     bool A_valid = false;  // A matches the configuration as of the last energy() (minus `dirty` atoms)
     double2 *C = nullptr;  // pair-coefficient tiles {c3, c5} (kernels_coef.h), the default sweep storage
+    double *energy_part = nullptr;      // [cap/64][2] per-block sums for U_pol and <rrms>
     size_t Ccap = 0;       // double2 elements
     bool C_valid = false;
+    bool pos_valid = false;  // px/py/pz/palpha/pflags match the configuration (moves are applied to both copies)
     int *d_slot = nullptr;  // device copy of slot_of_atom (padded with -1)
     std::vector<int> slot_of_atom;  // atom index -> view slot, -1 if not in the view
     double *es = nullptr, *mu0 = nullptr, *mu1 = nullptr, *munew = nullptr, *y = nullptr, *efind = nullptr,
@@ -130,6 +133,14 @@ struct mpmc_hip_ctx {
            *d_tmp3 = nullptr;
     unsigned long long *d_errmax = nullptr;
     bool have_polar_result = false;
+    // where the last polarization result lives (view order); scattered to atom order on demand
+    SweepView *result_view = nullptr;
+    const double *result_mu = nullptr;
+    bool results_scattered = true;
+    const double *energy_part = nullptr;  // per-block energy sums to fold in publish_result_kernel (or null)
+    bool es_stale = false;  // d_es (atom order) not yet reduced from the field partials
+    int es_slots = 0;
+    int energy_nt = 0;
     MoveList pending;               // coordinates handed over by update_atoms(), applied at the next energy()
     unsigned long long energy_calls = 0;
     std::vector<int> dirty_atoms;   // atoms moved by update_atoms() since the last energy()
@@ -142,6 +153,7 @@ struct mpmc_hip_ctx {
     int field_key = -1;             // mode / chunking the resident field partials were made with
     double *d_lrcpart = nullptr;    // scratch of the (cached) long-range correction
     DirtyBlocks dirty_blocks;       // of the energy() call in progress
+    double host_enqueue_s = 0.0, host_wait_s = 0.0;  // MPMC_HIP_HOST_PROFILE=1: printed at destroy
     bool box_ortho = false; // every off-diagonal basis entry is exactly zero
     int num_cus = 256;
     int opt_timing = 1;    // 0: no events, 1: sweep kernels + total only, 2: every kernel class
@@ -356,6 +368,7 @@ extern "C" int mpmc_hip_create(mpmc_hip_ctx **out, int device, int max_atoms) {
         DALLOC(v.rrms, np, double);
         DALLOC(v.ypart, 3 * np, double);
         DALLOC(v.gsflags, 2 + np / 64 + 2, unsigned);
+        DALLOC(v.energy_part, 2 * (np / 64 + 1), double);
         // slots past the last tile of a view are never written by the tiled sweep: keep them defined
         for (double *p : {v.mu0, v.mu1, v.munew, v.y, v.efind, v.efchg, v.es})
             HIPCHK(hipMemsetAsync(p, 0, 3 * np * sizeof(double), c->stream));
@@ -390,6 +403,9 @@ extern "C" int mpmc_hip_create(mpmc_hip_ctx **out, int device, int max_atoms) {
 
 extern "C" void mpmc_hip_destroy(mpmc_hip_ctx *c) {
     if (!c) return;
+    if (getenv("MPMC_HIP_HOST_PROFILE") && c->energy_calls)
+        fprintf(stderr, "MPMC_HIP host profile: %llu energy() calls, enqueue %.1f us, wait %.1f us per call\n",
+                c->energy_calls, 1e6 * c->host_enqueue_s / c->energy_calls, 1e6 * c->host_wait_s / c->energy_calls);
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->stream2) hipStreamSynchronize(c->stream2);
@@ -400,7 +416,7 @@ extern "C" void mpmc_hip_destroy(mpmc_hip_ctx *c) {
     for (void *p : dptrs)
         if (p) hipFree(p);
     for (SweepView &v : c->view) {
-        void *vp[] = {v.Srow, v.ypart, v.gsflags, v.d_idx, v.d_slot, v.px, v.py, v.pz, v.palpha, v.pflags, v.A,    v.C, v.es,
+        void *vp[] = {v.Srow, v.ypart, v.gsflags, v.d_idx, v.d_slot, v.px, v.py, v.pz, v.palpha, v.pflags, v.A,    v.C, v.energy_part, v.es,
                       v.mu0,   v.mu1, v.munew, v.y, v.efind, v.efchg, v.rrms};
         for (void *p : vp)
             if (p) hipFree(p);
@@ -574,6 +590,7 @@ extern "C" int mpmc_hip_upload(mpmc_hip_ctx *c, int n, const double *x, const do
     c->dirty_atoms.clear();
     c->view[0].A_valid = c->view[1].A_valid = false;
     c->view[0].C_valid = c->view[1].C_valid = false;
+    c->view[0].pos_valid = c->view[1].pos_valid = false;
     if (v0.nv > 0) HIPCHK(hipMemcpy(v0.d_idx, v0.h_idx.data(), v0.nv * sizeof(int), hipMemcpyHostToDevice));
     return 0;
 }
@@ -581,7 +598,9 @@ extern "C" int mpmc_hip_upload(mpmc_hip_ctx *c, int n, const double *x, const do
 // apply the queued single-molecule moves (kept in order with any staged copies)
 static int flush_moves(mpmc_hip_ctx *c) {
     if (c->pending.n > 0) {
-        hipLaunchKernelGGL(apply_moves_kernel, dim3(1), dim3(64), 0, c->stream, c->pending, c->d_x, c->d_y, c->d_z);
+        SweepView &v0 = c->view[0];
+        hipLaunchKernelGGL(apply_moves_kernel, dim3(1), dim3(64), 0, c->stream, c->pending, c->d_x, c->d_y, c->d_z,
+                           v0.d_slot, v0.px, v0.py, v0.pz);
         c->pending.n = 0;
     }
     return 0;
@@ -623,6 +642,7 @@ extern "C" int mpmc_hip_update_atoms(mpmc_hip_ctx *c, int first, int count, cons
         // nothing to launch yet
     } else if ((size_t)(3 * count) <= c->stage_cap) {
         if (flush_moves(c)) return -1;
+        c->view[0].pos_valid = false;
         // small delta (one molecule): stage in pinned memory so the copies are truly asynchronous and the
         // caller's buffers are free at once; the ring is recycled after the next energy() has synchronised
         if (c->stage_used + 3 * (size_t)count > c->stage_cap) {
@@ -639,6 +659,7 @@ extern "C" int mpmc_hip_update_atoms(mpmc_hip_ctx *c, int first, int count, cons
         HIPCHK(hipMemcpyAsync(c->d_z + first, s + 2 * count, b, hipMemcpyHostToDevice, c->stream));
     } else {
         if (flush_moves(c)) return -1;
+        c->view[0].pos_valid = false;
         HIPCHK(hipMemcpyAsync(c->d_x + first, x, b, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(c->d_y + first, y, b, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(c->d_z + first, z, b, hipMemcpyHostToDevice, c->stream));
@@ -789,12 +810,37 @@ static int ensure_view_matrix(SweepView &v) {
     return 0;
 }
 
+// E_static in atom order for every atom: the solver only reduces the partials of the polarizable atoms
+// (into its view); the full vector is made when a download or the ranked view needs it
+static int ensure_static_field(mpmc_hip_ctx *c) {
+    if (!c->es_stale) return 0;
+    hipLaunchKernelGGL(field_reduce_kernel, dim3(c->npad / 64), dim3(64 * kFieldGroups), 0, c->stream, c->d_fieldpart,
+                       c->es_slots, c->npad, c->d_es);
+    c->es_stale = false;
+    return 0;
+}
+
 #include "engine_polar.inc"
 
 // the 16-double result record goes straight into mapped pinned host memory (no copy engine / copy kernel)
 // followed by a sequence number the host spins on (no dependence on the device's sync-scheduling mode)
-__global__ void publish_result_kernel(const double *__restrict__ d_res, volatile double *__restrict__ h_res, int n,
-                                      double seq) {
+__global__ void publish_result_kernel(double *__restrict__ d_res, volatile double *__restrict__ h_res, int n,
+                                      double seq, const double *__restrict__ energy_part, int nt, int n_total) {
+    if (nt > 0) {
+        // U_pol and <rrms> from the per-block sums the fused sweep left (fixed order)
+        double e = 0.0, r = 0.0;
+        for (int t = threadIdx.x; t < nt; t += 64) {
+            e += energy_part[2 * t];
+            r += energy_part[2 * t + 1];
+        }
+        e = mpmc::wave_sum(e);
+        r = mpmc::wave_sum(r);
+        if (threadIdx.x == 0) {
+            d_res[R_UPOL] = -0.5 * e;
+            d_res[R_RRMS] = r / (double)n_total;  // mean over ALL atoms (polar.c:21-27)
+        }
+        __syncthreads();
+    }
     if ((int)threadIdx.x < n) h_res[threadIdx.x] = d_res[threadIdx.x];
     __threadfence_system();
     if (threadIdx.x == 0) h_res[n] = seq;
@@ -816,6 +862,8 @@ extern "C" int mpmc_hip_energy(mpmc_hip_ctx *c, mpmc_hip_result *out) {
     c->ev_next = 0;
     c->recs.clear();
     ++c->energy_calls;
+    timespec ts0, ts1, ts2;
+    clock_gettime(CLOCK_MONOTONIC, &ts0);
     if (flush_moves(c)) return -1;
     if (c->opt_timing >= 2 || (c->opt_timing == 1 && (c->energy_calls & 3ull) == 0ull))
         hipEventRecord(c->ev_first, c->stream);
@@ -891,7 +939,7 @@ extern "C" int mpmc_hip_energy(mpmc_hip_ctx *c, mpmc_hip_result *out) {
             // tile partials persist: after a single-molecule move only the tiles of the moved atoms' blocks
             DirtyBlocks sel = dirty_blocks;
             if (!c->pair_part_valid) sel.n = 0;
-            const dim3 grid(ntile, sel.n > 0 ? sel.n : ntile), block(64);
+            const dim3 grid(ntile, sel.n > 0 ? sel.n : ntile), block(64 * kPairWaves);
             if (c->pair_part_valid && c->dirty_atoms.empty())
                 ;  // nothing moved since the partials were made
             else if (pp.fh_order == 0)
@@ -935,12 +983,13 @@ extern "C" int mpmc_hip_energy(mpmc_hip_ctx *c, mpmc_hip_result *out) {
     const bool timed_call = c->opt_timing >= 2 || (c->opt_timing == 1 && (c->energy_calls & 3ull) == 0ull);
     if (timed_call) hipEventRecord(c->ev_last, c->stream);
     hipLaunchKernelGGL(publish_result_kernel, dim3(1), dim3(64), 0, c->stream, c->d_res, c->h_res_dev, (int)R_COUNT,
-                       (double)c->energy_calls);
+                       (double)c->energy_calls, do_polar ? c->energy_part : nullptr, do_polar ? c->energy_nt : 0, c->n);
     c->h_gserr[0] = c->h_gserr[1] = 0;
     for (int v = 0; v < 2; ++v)
         if (c->gs_used[v])
             HIPCHK(hipMemcpyAsync(c->h_gserr + v, c->view[v].gsflags + 1, sizeof(unsigned), hipMemcpyDeviceToHost,
                                   c->stream));
+    clock_gettime(CLOCK_MONOTONIC, &ts1);
     {
         // spin on the sequence number the publish kernel writes last; fall back to a stream sync if it
         // does not show up (also surfaces launch errors)
@@ -957,6 +1006,9 @@ extern "C" int mpmc_hip_energy(mpmc_hip_ctx *c, mpmc_hip_result *out) {
         }
         if (!seen) HIPCHK(hipStreamSynchronize(c->stream));
     }
+    clock_gettime(CLOCK_MONOTONIC, &ts2);
+    c->host_enqueue_s += (ts1.tv_sec - ts0.tv_sec) + 1e-9 * (ts1.tv_nsec - ts0.tv_nsec);
+    c->host_wait_s += (ts2.tv_sec - ts1.tv_sec) + 1e-9 * (ts2.tv_nsec - ts1.tv_nsec);
     const bool gs_timeout = (c->h_gserr[0] | c->h_gserr[1]) != 0;
     c->gs_used[0] = c->gs_used[1] = false;
     if (gs_timeout) {
@@ -1006,6 +1058,15 @@ extern "C" int mpmc_hip_download_dipoles(mpmc_hip_ctx *c, double *mu, double *ef
     if (!c || !c->have_atoms) return fail("MPMC_HIP: download_dipoles: no configuration");
     if (!c->have_polar_result) return fail("MPMC_HIP: download_dipoles: no polarization energy evaluated yet");
     HIPCHK(hipSetDevice(c->device));
+    if (ensure_static_field(c)) return -1;
+    if (!c->results_scattered) {
+        // the solver works on the compacted polarizable atoms; atom order is produced when somebody asks
+        SweepView *V = c->result_view;
+        hipLaunchKernelGGL(scatter_results_kernel, dim3((c->npad + 255) / 256), dim3(256), 0, c->stream, c->npad,
+                           V->d_slot, c->result_mu, V->efind, V->efchg, c->d_mu, c->d_efind, c->d_efchg);
+        HIPCHK(hipStreamSynchronize(c->stream));
+        c->results_scattered = true;
+    }
     const size_t b = 3 * (size_t)c->n * sizeof(double);
     if (mu) HIPCHK(hipMemcpy(mu, c->d_mu, b, hipMemcpyDeviceToHost));
     if (ef_static) HIPCHK(hipMemcpy(ef_static, c->d_es, b, hipMemcpyDeviceToHost));

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(64) void update_coef_kernel(DevAtoms a, DevBox bx, 
 // lane each, 1 KiB per wave-instruction, non-temporal) are issued up front.  The four quarters are
 // combined through LDS; the tile's row sums go to Srow[tj][192 ti + 64 p + l], its column sums to
 // Zcol[ti][192 tj + 64 p + l] (p = component; planar inside a 64-atom block so that stores and the
-// finish kernel's loads are coalesced).  Everything is summed in a fixed order => deterministic.
+// finishing loads are coalesced).  Everything is summed in a fixed order => deterministic.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void upper_tile_of(int t, int nt, int &ti, int &tj) {
     // rows ti = 0, 1, ... hold nt, nt - 1, ... tiles; first tile of row ti is t0(ti) = ti nt - ti (ti - 1) / 2
@@ -161,6 +161,148 @@ __device__ __forceinline__ void upper_tile_of(int t, int nt, int &ti, int &tj) {
     while ((r + 1) * nt - (r + 1) * r / 2 <= t) ++r;
     ti = r;
     tj = r + (t - (r * nt - r * (r - 1) / 2));
+}
+
+// Operands of the finishing step of a sweep (the epilogue of sweep_kernel: new mu, SOR/ESOR mix, RRMS,
+// max-change | Palmo), which also leaves each block's share of U_pol = -1/2 sum mu.(E_static [+ dE_ind])
+// and of the RRMS sum (polar.c:13-28, :107-116) for the publish kernel to fold.
+struct CoefFinish {
+    const double *alpha;
+    const int *flags;
+    const double *mu_in;
+    const double *es;
+    double *ef_induced;
+    double *out;               // mu_out (Jacobi) | dE_ind (Palmo)
+    double *rrms;
+    unsigned long long *errmax;
+    const double *mu_final;    // Palmo: the dipoles the energy is taken with
+    double *energy_part;       // [nt][2]: sum_i mu.E, sum_i rrms_i of the block
+    SweepParams sp;
+};
+
+// y_i = sum_{tj >= t} Srow[tj][block t] + sum_{ti < t} Zcol[ti][block t]  (nt terms, fixed order), then the
+// epilogue.  grid = nt; block = 1024 = 64 atoms x 16 term groups, combined through LDS.
+//
+// (Folding this into the sweep -- the last workgroup to feed a block finishes it, found through a
+// counter -- was tried and lost: the release/acquire it needs between workgroups on different XCDs
+// costs either a whole-L2 write-back + invalidate per workgroup (250 us per sweep) or, with
+// write-through stores and a returning atomic, ~3 us of exposed latency per workgroup (+15 us per
+// sweep), against ~7 us for this launch.)
+constexpr int kCoefFinishGroups = 16;
+template <int MODE>
+__global__ __launch_bounds__(64 * kCoefFinishGroups) void pair_finish_kernel(int nt, const double *__restrict__ Srow,
+                                                                              const double *__restrict__ Zcol,
+                                                                              CoefFinish f) {
+    const int t = blockIdx.x;
+    __shared__ double part[kCoefFinishGroups][3][64];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int i = 64 * t + lane;
+    const size_t ncol = 3 * (size_t)kCoefTile * nt;
+    // the epilogue's operands are requested up front, so their latency overlaps the partial-sum loads
+    double al = 0.0, old[3] = {0.0, 0.0, 0.0}, es[3] = {0.0, 0.0, 0.0}, aux[3] = {0.0, 0.0, 0.0};
+    int fl = 0;
+    if (g == 0) {
+        al = f.alpha[i];
+        fl = f.flags[i];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            es[p] = f.es[3 * i + p];
+            if (MODE == kSweepJacobi) {
+                old[p] = f.mu_in[3 * i + p];
+            } else {
+                old[p] = f.mu_final[3 * i + p];
+                aux[p] = f.ef_induced[3 * i + p];
+            }
+        }
+    }
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    // four terms per trip, loads issued together (a term's address does not depend on data)
+    for (int u0 = g; u0 < nt; u0 += 4 * kCoefFinishGroups) {
+        double v[4][3];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int u = u0 + k * kCoefFinishGroups;
+            const bool on = u < nt;
+            const int uu = on ? u : g;
+            // u < nt - t: row partial of tile (t, t + u); otherwise column partial of tile (u - (nt - t), t)
+            const double *p = (uu < nt - t) ? Srow + (size_t)(t + uu) * ncol : Zcol + (size_t)(uu - (nt - t)) * ncol;
+            p += 192 * t + lane;
+            v[k][0] = on ? p[0] : 0.0;
+            v[k][1] = on ? p[64] : 0.0;
+            v[k][2] = on ? p[128] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            s0 += v[k][0];
+            s1 += v[k][1];
+            s2 += v[k][2];
+        }
+    }
+    part[g][0][lane] = s0;
+    part[g][1][lane] = s1;
+    part[g][2][lane] = s2;
+    __syncthreads();
+    if (g != 0) return;
+    double s[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < kCoefFinishGroups; ++k) acc += part[k][p][lane];
+        s[p] = acc;
+    }
+    const bool valid = fl & kValid;
+    double e_i = 0.0, r_i = 0.0;
+    if ((MODE == kSweepJacobi && (al == 0.0 || !valid)) || (MODE == kSweepPalmo && !valid)) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            f.out[3 * i + p] = 0.0;
+            if (MODE == kSweepJacobi) f.ef_induced[3 * i + p] = 0.0;
+        }
+        if (MODE == kSweepJacobi && f.sp.want_rrms) f.rrms[i] = 0.0;
+    } else if (MODE == kSweepJacobi) {
+        double d2 = 0.0, n2 = 0.0, emax = 0.0, m[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const double e = -s[p];
+            const double nw = al * (es[p] + e);
+            f.ef_induced[3 * i + p] = e;
+            m[p] = f.sp.w_new * nw + f.sp.w_old * old[p];
+            f.out[3 * i + p] = m[p];
+            const double d = nw - old[p];
+            d2 += d * d;
+            n2 += nw * nw;
+            emax = fmax(emax, d * d);
+        }
+        if (f.sp.want_rrms) {
+            double rr = sqrt(d2 / n2);  // calc_dipole_rrms, thole_iterative.c:61-77
+            if (!isfinite(rr)) rr = 0.0;
+            f.rrms[i] = rr;
+            r_i = rr;
+        }
+        // are_we_done_yet (thole_iterative.c:104-113) needs max (new-old)^2: non-negative doubles order like
+        // their bit patterns, so an integer atomicMax is exact and order-independent.
+        atomicMax(f.errmax + f.sp.err_slot, (unsigned long long)__double_as_longlong(emax));
+        e_i = m[0] * es[0] + m[1] * es[1] + m[2] * es[2];
+    } else {
+        double m[3], dc[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            dc[p] = -aux[p] - s[p];
+            f.out[3 * i + p] = dc[p];
+            m[p] = old[p];
+        }
+        e_i = m[0] * es[0] + m[1] * es[1] + m[2] * es[2];
+        e_i += m[0] * dc[0] + m[1] * dc[1] + m[2] * dc[2];
+        const double rr = f.rrms[i];
+        r_i = isfinite(rr) ? rr : 0.0;
+    }
+    e_i = wave_sum(e_i);
+    r_i = wave_sum(r_i);
+    if (lane == 0) {
+        f.energy_part[2 * t] = e_i;
+        f.energy_part[2 * t + 1] = r_i;
+    }
 }
 
 template <int ORTHO>
@@ -237,98 +379,6 @@ __global__ __launch_bounds__(64 * kCoefWaves) void pair_sweep_kernel(const doubl
             for (int q = 0; q < kCoefWaves; ++q) s += red[q][3 + p][l];
             Zcol[(size_t)ti * ncol + 192 * tj + 64 * p + l] = s;
         }
-    }
-}
-
-// y_i = sum_{tj >= t} Srow[tj][block t] + sum_{ti < t} Zcol[ti][block t]  (t = i / 64; nt terms, fixed
-// order), then the sweep epilogue of sweep_kernel (new mu, SOR/ESOR mix, RRMS, max-change | Palmo).
-// grid = nt; block = 1024 = 64 atoms x 16 term groups, combined through LDS.
-constexpr int kCoefFinishGroups = 16;
-template <int MODE>
-__global__ __launch_bounds__(1024) void pair_finish_kernel(int nt, const double *__restrict__ Srow,
-                                                            const double *__restrict__ Zcol,
-                                                            const double *__restrict__ alpha,
-                                                            const int *__restrict__ flags,
-                                                            const double *__restrict__ mu_in,
-                                                            const double *__restrict__ es,
-                                                            double *__restrict__ ef_induced, double *__restrict__ out,
-                                                            double *__restrict__ rrms,
-                                                            unsigned long long *__restrict__ errmax, SweepParams sp) {
-    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int t = blockIdx.x;
-    const int i = 64 * t + lane;
-    const size_t ncol = 3 * (size_t)kCoefTile * nt;
-    __shared__ double part[kCoefFinishGroups][3][64];
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-    // four terms per trip, loads issued together (a term's address does not depend on data)
-    for (int u0 = g; u0 < nt; u0 += 4 * kCoefFinishGroups) {
-        double v[4][3];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int u = u0 + k * kCoefFinishGroups;
-            const bool on = u < nt;
-            const int uu = on ? u : g;
-            // u < nt - t: row partial of tile (t, t + u); otherwise column partial of tile (u - (nt - t), t)
-            const double *p = (uu < nt - t) ? Srow + (size_t)(t + uu) * ncol : Zcol + (size_t)(uu - (nt - t)) * ncol;
-            p += 192 * t + lane;
-            v[k][0] = on ? p[0] : 0.0;
-            v[k][1] = on ? p[64] : 0.0;
-            v[k][2] = on ? p[128] : 0.0;
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            s0 += v[k][0];
-            s1 += v[k][1];
-            s2 += v[k][2];
-        }
-    }
-    part[g][0][lane] = s0;
-    part[g][1][lane] = s1;
-    part[g][2][lane] = s2;
-    __syncthreads();
-    if (g != 0) return;
-    double s[3];
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-        double acc = 0.0;
-#pragma unroll
-        for (int k = 0; k < kCoefFinishGroups; ++k) acc += part[k][p][lane];
-        s[p] = acc;
-    }
-    const double al = alpha[i];
-    const bool valid = flags[i] & kValid;
-    if ((MODE == kSweepJacobi && (al == 0.0 || !valid)) || (MODE == kSweepPalmo && !valid)) {
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            out[3 * i + p] = 0.0;
-            if (MODE == kSweepJacobi) ef_induced[3 * i + p] = 0.0;
-        }
-        if (MODE == kSweepJacobi && sp.want_rrms) rrms[i] = 0.0;
-        return;
-    }
-    if (MODE == kSweepJacobi) {
-        double d2 = 0.0, n2 = 0.0, emax = 0.0;
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            const double e = -s[p];
-            const double old = mu_in[3 * i + p];
-            const double nw = al * (es[3 * i + p] + e);
-            ef_induced[3 * i + p] = e;
-            out[3 * i + p] = sp.w_new * nw + sp.w_old * old;
-            const double d = nw - old;
-            d2 += d * d;
-            n2 += nw * nw;
-            emax = fmax(emax, d * d);
-        }
-        if (sp.want_rrms) {
-            double rr = sqrt(d2 / n2);  // calc_dipole_rrms, thole_iterative.c:61-77
-            if (!isfinite(rr)) rr = 0.0;
-            rrms[i] = rr;
-        }
-        atomicMax(errmax + sp.err_slot, (unsigned long long)__double_as_longlong(emax));
-    } else {
-#pragma unroll
-        for (int p = 0; p < 3; ++p) out[3 * i + p] = -ef_induced[3 * i + p] - s[p];
     }
 }
 

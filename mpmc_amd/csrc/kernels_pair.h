@@ -50,11 +50,17 @@ __device__ __forceinline__ void load_jtile(JTile &t, const DevAtoms &a, int j0, 
 // {sel.blk[y], x}, lower block as the row tile as in the full pass; every other tile keeps its partial
 // from the previous call (the reference keeps per-pair energies and recalculates only the pairs an MC
 // move touched, pairs.c:238-249 / lj.c:182; here the cached unit is a 64 x 64 tile).
+// Workgroup = kPairWaves waves on one 64 x 64 tile: every wave has lane = row atom i and takes 64/kPairWaves
+// of the column atoms (a lone wave needs ~40 us for a tile -- erfc/exp/divides of the FH path -- which
+// would be the critical path of an incremental pass that has far fewer tiles than the chip has CUs).
+constexpr int kPairWaves = 8;
+constexpr int kPairJPerWave = kWave / kPairWaves;
 template <int FH>
-__global__ __launch_bounds__(64) void pair_rd_es_kernel(DevAtoms a, DevBox bx, PairParams pp, DirtyBlocks sel,
-                                                         double *__restrict__ partials) {
+__global__ __launch_bounds__(64 * kPairWaves) void pair_rd_es_kernel(DevAtoms a, DevBox bx, PairParams pp,
+                                                                      DirtyBlocks sel,
+                                                                      double *__restrict__ partials) {
     int I = blockIdx.y, J = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (sel.n > 0) {
         const int d = sel.blk[blockIdx.y], o = blockIdx.x;
         for (int k = 0; k < (int)blockIdx.y; ++k)
@@ -64,11 +70,12 @@ __global__ __launch_bounds__(64) void pair_rd_es_kernel(DevAtoms a, DevBox bx, P
     }
     double *out = partials + (size_t)(I * gridDim.x + J) * kPairChannels;
     if (J < I) {
-        if (lane < kPairChannels) out[lane] = 0.0;
+        if (threadIdx.x < kPairChannels) out[threadIdx.x] = 0.0;
         return;
     }
     __shared__ JTile t;
-    load_jtile(t, a, J * kWave, lane);
+    __shared__ double red[kPairWaves][3];
+    if (wv == 0) load_jtile(t, a, J * kWave, lane);
     __syncthreads();
 
     const int i = I * kWave + lane;
@@ -85,7 +92,7 @@ __global__ __launch_bounds__(64) void pair_rd_es_kernel(DevAtoms a, DevBox bx, P
     // Phase 1: flag tests + fp32 distance screen -> candidate bit per partner; phase 2: exact path for
     // the set bits only (see static_field_kernel for why the loops are split).
     unsigned long long cand = 0ull;
-    for (int jj = 0; jj < kWave; ++jj) {
+    for (int jj = wv * kPairJPerWave; jj < (wv + 1) * kPairJPerWave; ++jj) {
         const int j = J * kWave + jj;
         const int flj = t.flags[jj];
         // pair (i<j), both real atoms, not frozen-frozen (lj.c:193, coulombic.c:165)
@@ -184,9 +191,17 @@ __global__ __launch_bounds__(64) void pair_rd_es_kernel(DevAtoms a, DevBox bx, P
     e_es = wave_sum(e_es);
     e_intra = wave_sum(e_intra);
     if (lane == 0) {
-        out[0] = e_rd;
-        out[1] = e_es;
-        out[2] = e_intra;
+        red[wv][0] = e_rd;
+        red[wv][1] = e_es;
+        red[wv][2] = e_intra;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < kPairWaves; ++k) s += red[k][threadIdx.x];
+        out[threadIdx.x] = s;
+    } else if (threadIdx.x == 3) {
         out[3] = 0.0;
     }
 }

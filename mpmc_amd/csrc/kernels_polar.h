@@ -33,10 +33,15 @@ struct FieldParams {
 // Incremental pass (sel.n > 0): grid = (max(nchunk, npad/64), sel.n, 2); z = 0 recomputes the partials of
 // the dirty block's atoms against every chunk, z = 1 those of every atom against the dirty block's chunk.
 // All other partials persist from the previous call (same values a full pass would write).
+// Workgroup = kFieldWaves waves on one (chunk, tile): every wave has lane = atom i and takes
+// 64/kFieldWaves of each staged group of partners; the waves' sums are combined in a fixed order.
+constexpr int kFieldWaves = 8;
+constexpr int kFieldJPerWave = kWave / kFieldWaves;
 template <int MODE>
-__global__ __launch_bounds__(64) void static_field_kernel(DevAtoms a, DevBox bx, FieldParams fp, DirtyBlocks sel,
-                                                           double *__restrict__ part) {
-    const int lane = threadIdx.x;
+__global__ __launch_bounds__(64 * kFieldWaves) void static_field_kernel(DevAtoms a, DevBox bx, FieldParams fp,
+                                                                         DirtyBlocks sel,
+                                                                         double *__restrict__ part) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int tile = blockIdx.y, chunk = blockIdx.x;
     if (sel.n > 0) {
         const int d = sel.blk[blockIdx.y];
@@ -54,6 +59,7 @@ __global__ __launch_bounds__(64) void static_field_kernel(DevAtoms a, DevBox bx,
     __shared__ double sx[kWave], sy[kWave], sz[kWave], sq[kWave];
     __shared__ float fx[kWave], fy[kWave], fz[kWave];  // fp32 copies for the screening pass
     __shared__ int smol[kWave], sfl[kWave];
+    __shared__ double red[kFieldWaves][3][kWave];
 
     const double xi = a.x[i], yi = a.y[i], zi = a.z[i];
     const float xif = (float)xi, yif = (float)yi, zif = (float)zi;
@@ -66,22 +72,24 @@ __global__ __launch_bounds__(64) void static_field_kernel(DevAtoms a, DevBox bx,
 
     for (int j0 = jbeg; j0 < jbeg + fp.chunk && j0 < a.npad; j0 += kWave) {
         __syncthreads();
-        sx[lane] = a.x[j0 + lane];
-        sy[lane] = a.y[j0 + lane];
-        sz[lane] = a.z[j0 + lane];
-        fx[lane] = (float)sx[lane];
-        fy[lane] = (float)sy[lane];
-        fz[lane] = (float)sz[lane];
-        sq[lane] = a.q[j0 + lane];
-        smol[lane] = a.mol[j0 + lane];
-        sfl[lane] = (sq[lane] != 0.0) ? a.flags[j0 + lane] : 0;  // uncharged partners never contribute a field
+        if (wv == 0) {
+            sx[lane] = a.x[j0 + lane];
+            sy[lane] = a.y[j0 + lane];
+            sz[lane] = a.z[j0 + lane];
+            fx[lane] = (float)sx[lane];
+            fy[lane] = (float)sy[lane];
+            fz[lane] = (float)sz[lane];
+            sq[lane] = a.q[j0 + lane];
+            smol[lane] = a.mol[j0 + lane];
+            sfl[lane] = (sq[lane] != 0.0) ? a.flags[j0 + lane] : 0;  // uncharged partners never contribute a field
+        }
         __syncthreads();
         // Phase 1 (cheap, uniform): flag tests + fp32 distance screen for all 64 partners -> one bit each.
         // Phase 2 (expensive, sparse): the exact fp64 path only for the set bits.  Done as two loops
         // because a wave executes a divergent branch whenever ANY lane takes it: with ~3 % of the pairs
         // inside the cutoff a fused loop still ran the exact path in ~86 % of its iterations.
         unsigned long long cand = 0ull;
-        for (int jj = 0; jj < kWave; ++jj) {
+        for (int jj = wv * kFieldJPerWave; jj < (wv + 1) * kFieldJPerWave; ++jj) {
             const int j = j0 + jj;
             const int flj = sfl[jj];
             bool act = (j != i) && (fli & kValid) && (flj & kValid) && !((fli & kFrozen) && (flj & kFrozen));
@@ -130,10 +138,16 @@ __global__ __launch_bounds__(64) void static_field_kernel(DevAtoms a, DevBox bx,
             }
         }
     }
-    const size_t base = (size_t)chunk * 3 * a.npad;
-    part[base + i] = ex;
-    part[base + a.npad + i] = ey;
-    part[base + 2 * (size_t)a.npad + i] = ez;
+    red[wv][0][lane] = ex;
+    red[wv][1][lane] = ey;
+    red[wv][2][lane] = ez;
+    __syncthreads();
+    if (wv < 3) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < kFieldWaves; ++k) s += red[k][wv][lane];
+        part[(size_t)chunk * 3 * a.npad + (size_t)wv * a.npad + i] = s;
+    }
 }
 
 // Reciprocal part of the Ewald static field (recip_term(), polar_ewald.c:85-132):
@@ -194,23 +208,52 @@ __global__ __launch_bounds__(64) void ewald_field_recip_kernel(DevAtoms a, const
     part[base + 2 * (size_t)a.npad + i] = valid ? ez * scale : 0.0;
 }
 
-// es[3i+p] = sum over chunks (fixed order) [+ accumulate into existing when add != 0]
-__global__ __launch_bounds__(64) void field_reduce_kernel(const double *__restrict__ part, int nchunk, int npad,
-                                                           double *__restrict__ es, int add) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= npad) return;
-    double a0 = add ? es[3 * i] : 0.0, a1 = add ? es[3 * i + 1] : 0.0, a2 = add ? es[3 * i + 2] : 0.0;
+// Field of one atom from the per-chunk partials, [slot][3][npad]: group g of kFieldGroups sums the slots
+// c = g, g + G, ... in increasing order, the group sums are then added in order g = 0 .. G-1 (through
+// LDS).  Workgroup = 64 atoms x kFieldGroups; returns the three sums to the threads of group 0.
+constexpr int kFieldGroups = 8;
+__device__ __forceinline__ void reduce_field_partials(const double *__restrict__ part, int nslots, int npad, int atom,
+                                                      double (*red)[3][kWave], double e[3]) {
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
     const size_t np = (size_t)npad;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    if (atom >= 0) {
 #pragma unroll 4
-    for (int c = 0; c < nchunk; ++c) {
-        const double *p = part + (size_t)c * 3 * np + i;
-        a0 += p[0];
-        a1 += p[np];
-        a2 += p[2 * np];
+        for (int c = g; c < nslots; c += kFieldGroups) {
+            const double *q = part + (size_t)c * 3 * np + atom;
+            a0 += q[0];
+            a1 += q[np];
+            a2 += q[2 * np];
+        }
     }
-    es[3 * i] = a0;
-    es[3 * i + 1] = a1;
-    es[3 * i + 2] = a2;
+    red[g][0][lane] = a0;
+    red[g][1][lane] = a1;
+    red[g][2][lane] = a2;
+    __syncthreads();
+    if (g == 0) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < kFieldGroups; ++k) s += red[k][p][lane];
+            e[p] = s;
+        }
+    }
+}
+
+// es[3i+p] for every atom (atom order); only needed when somebody downloads the static field.
+// grid = npad/64; block = 64 * kFieldGroups.
+__global__ __launch_bounds__(64 * kFieldGroups) void field_reduce_kernel(const double *__restrict__ part, int nslots,
+                                                                          int npad, double *__restrict__ es) {
+    __shared__ double red[kFieldGroups][3][kWave];
+    const int i = blockIdx.x * kWave + (threadIdx.x & 63);
+    double e[3];
+    reduce_field_partials(part, nslots, npad, i, red, e);
+    if ((threadIdx.x >> 6) == 0) {
+        es[3 * i] = e[0];
+        es[3 * i + 1] = e[1];
+        es[3 * i + 2] = e[2];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -338,12 +381,22 @@ struct MoveList {
 };
 
 __global__ __launch_bounds__(64) void apply_moves_kernel(MoveList m, double *__restrict__ x, double *__restrict__ y,
-                                                          double *__restrict__ z) {
+                                                          double *__restrict__ z, const int *__restrict__ slot_of_atom,
+                                                          double *__restrict__ px, double *__restrict__ py,
+                                                          double *__restrict__ pz) {
     const int e = threadIdx.x;
     if (e < m.n) {  // entries are unique per atom (the host merges repeated updates)
-        x[m.idx[e]] = m.x[e];
-        y[m.idx[e]] = m.y[e];
-        z[m.idx[e]] = m.z[e];
+        const int a = m.idx[e];
+        x[a] = m.x[e];
+        y[a] = m.y[e];
+        z[a] = m.z[e];
+        // the compacted copy the polarization kernels read (sweep view 0) follows along
+        const int s = slot_of_atom[a];
+        if (s >= 0) {
+            px[s] = m.x[e];
+            py[s] = m.y[e];
+            pz[s] = m.z[e];
+        }
     }
 }
 
@@ -546,23 +599,31 @@ __global__ __launch_bounds__(256) void init_dipoles_kernel(int npad, const doubl
 
 // Same, fused with the gather of E_static into the sweep view and the reset of the per-call
 // convergence words (one launch instead of four).
-__global__ __launch_bounds__(256) void init_view_kernel(int nv, int nvpad, const int *__restrict__ idx,
-                                                         const double *__restrict__ alpha,
-                                                         const double *__restrict__ es_full, double scale,
-                                                         double *__restrict__ es, double *__restrict__ mu,
-                                                         double *__restrict__ ef_induced,
-                                                         double *__restrict__ ef_change, double *__restrict__ rrms,
-                                                         unsigned long long *__restrict__ errmax) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < 256) errmax[k] = 0ull;
-    if (k >= nvpad) return;
-    const double al = alpha[k];
+// init_dipoles (thole_iterative.c:13-25) for the sweep view, fused with the reduction of the static-field
+// partials of the view's atoms: E_static,k = sum over partial slots (see reduce_field_partials),
+// mu_k = alpha_k E_static,k * scale; clears the per-call scratch (E_ind, dE_ind, rrms, errmax).
+// grid = nvpad/64; block = 64 * kFieldGroups.
+__global__ __launch_bounds__(64 * kFieldGroups) void init_view_kernel(int nv, int nvpad, const int *__restrict__ idx,
+                                                                       const double *__restrict__ alpha,
+                                                                       const double *__restrict__ part, int nslots,
+                                                                       int npad, double scale, double *__restrict__ es,
+                                                                       double *__restrict__ mu,
+                                                                       double *__restrict__ ef_induced,
+                                                                       double *__restrict__ ef_change,
+                                                                       double *__restrict__ rrms,
+                                                                       unsigned long long *__restrict__ errmax) {
+    __shared__ double red[kFieldGroups][3][kWave];
+    const int k = blockIdx.x * kWave + (threadIdx.x & 63);
+    if (blockIdx.x == 0 && threadIdx.x < 256) errmax[threadIdx.x] = 0ull;
     const int src = (k < nv) ? idx[k] : -1;
+    double e[3];
+    reduce_field_partials(part, nslots, npad, src, red, e);
+    if ((threadIdx.x >> 6) != 0) return;
+    const double al = alpha[k];
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
-        const double e = (src >= 0) ? es_full[3 * src + p] : 0.0;
-        es[3 * k + p] = e;
-        mu[3 * k + p] = al * e * scale;
+        es[3 * k + p] = e[p];
+        mu[3 * k + p] = al * e[p] * scale;
         ef_induced[3 * k + p] = 0.0;
         ef_change[3 * k + p] = 0.0;
     }
