@@ -19,6 +19,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <ctime>
 #include <numeric>
 #include <string>
@@ -153,6 +154,7 @@ struct mpmc_hip_ctx {
     int field_key = -1;             // mode / chunking the resident field partials were made with
     double *d_lrcpart = nullptr;    // scratch of the (cached) long-range correction
     DirtyBlocks dirty_blocks;       // of the energy() call in progress
+    std::function<void()> enqueue_side;  // set while run_polarization() may feed the side stream (see energy())
     double host_enqueue_s = 0.0, host_wait_s = 0.0;  // MPMC_HIP_HOST_PROFILE=1: printed at destroy
     bool box_ortho = false; // every off-diagonal basis entry is exactly zero
     int num_cus = 256;
@@ -827,7 +829,7 @@ static int ensure_static_field(mpmc_hip_ctx *c) {
 __global__ void publish_result_kernel(double *__restrict__ d_res, volatile double *__restrict__ h_res, int n,
                                       double seq, const double *__restrict__ energy_part, int nt, int n_total) {
     if (nt > 0) {
-        // U_pol and <rrms> from the per-block sums the fused sweep left (fixed order)
+        // U_pol and <rrms> from the per-block sums the finish step left (fixed order)
         double e = 0.0, r = 0.0;
         for (int t = threadIdx.x; t < nt; t += 64) {
             e += energy_part[2 * t];
@@ -904,20 +906,23 @@ extern "C" int mpmc_hip_energy(mpmc_hip_ctx *c, mpmc_hip_result *out) {
     }
 
     const bool do_polar = !P.rd_only && P.polarization;
-    // Enqueue order: the host needs ~5 us per launch, and the polarization chain is the critical path, so
-    // with a fixed iteration count its ~15 launches go first and the side-stream kernels (which have
-    // ~200 us of slack) after; in precision mode the chain synchronises with the host every iteration, so
-    // the side stream is fed first.
+    // Enqueue order: the host needs ~3 us per launch and the polarization chain is the critical path, so
+    // with a fixed iteration count the chain is enqueued up to its first sweep (by then the device has
+    // ~40 us of work queued), then the side-stream kernels, then the remaining sweeps; in precision mode
+    // the chain synchronises with the host every iteration, so the side stream is fed first.
     const bool polar_first = do_polar && c->opt_overlap && P.polar_precision == 0.0;
-    for (int phase = 0; phase < 2; ++phase) {
-        const bool side_now = (phase == 0) ? !polar_first : polar_first;
-        if (side_now) {
+    int side_rc = 0;
+    bool side_done = false;
+    auto enqueue_side = [&]() {
+        if (side_done) return;
+        side_done = true;
+        side_rc = [&]() -> int {
         // ---- LJ long-range correction: parameters + volume only => cached (lj.c:56-107)
         if (P.rd_lrc) {
             if (!c->lrc_valid) {
                 ScopedTimer t(c, T_OTHER, sb);
                 hipLaunchKernelGGL(lj_lrc_kernel, dim3(ntile, ntile), dim3(64), 0, sb, a, bx, c->d_lrcpart);
-                hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, sb, c->d_lrcpart, ntile * ntile, 1,
+                hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(kReduceThreads), 0, sb, c->d_lrcpart, ntile * ntile, 1,
                                    c->d_res + R_LRC);
                 c->lrc_valid = true;
             }
@@ -949,7 +954,7 @@ extern "C" int mpmc_hip_energy(mpmc_hip_ctx *c, mpmc_hip_result *out) {
             else
                 hipLaunchKernelGGL(pair_rd_es_kernel<4>, grid, block, 0, sb, a, bx, pp, sel, c->d_pairpart);
             c->pair_part_valid = true;
-            hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, sb, c->d_pairpart, ntile * ntile,
+            hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(kReduceThreads), 0, sb, c->d_pairpart, ntile * ntile,
                                kPairChannels, c->d_res + R_RD_PAIR);
         }
 
@@ -958,7 +963,7 @@ extern "C" int mpmc_hip_energy(mpmc_hip_ctx *c, mpmc_hip_result *out) {
             ScopedTimer t(c, T_RECIP, sb);
             if (c->nk > 0) {
                 hipLaunchKernelGGL(ewald_recip_kernel, dim3(c->nk), dim3(256), 0, sb, a, c->d_kvec, c->d_perk);
-                hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, sb, c->d_perk, c->nk, 1,
+                hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(kReduceThreads), 0, sb, c->d_perk, c->nk, 1,
                                    c->d_res + R_RECIP);
             } else {
                 HIPCHK(hipMemsetAsync(c->d_res + R_RECIP, 0, sizeof(double), sb));
@@ -968,17 +973,27 @@ extern "C" int mpmc_hip_energy(mpmc_hip_ctx *c, mpmc_hip_result *out) {
             HIPCHK(hipMemsetAsync(c->d_res + R_RECIP, 0, 2 * sizeof(double), sb));
         }
         if (c->opt_overlap) hipEventRecord(c->ev_join, sb);
-        } else {
+        return 0;
+        }();
+    };
+    c->enqueue_side = polar_first ? std::function<void()>(enqueue_side) : std::function<void()>();
+    if (!polar_first) enqueue_side();
+    {
         // ---- polarization (main stream)
         if (do_polar) {
-            if (run_polarization(c, a, bx, &polar_iterations, &iter_success)) return -1;
+            if (run_polarization(c, a, bx, &polar_iterations, &iter_success)) {
+                c->enqueue_side = nullptr;
+                return -1;
+            }
         } else {
             HIPCHK(hipMemsetAsync(c->d_res + R_UPOL, 0, 2 * sizeof(double), c->stream));
         }
         // the resident A only tracks moves while it is being maintained
         if (!do_polar || P.polar_zodid) c->view[0].A_valid = c->view[0].C_valid = false;
-        }
     }
+    c->enqueue_side = nullptr;
+    enqueue_side();
+    if (side_rc) return -1;
     if (c->opt_overlap) hipStreamWaitEvent(c->stream, c->ev_join, 0);
     const bool timed_call = c->opt_timing >= 2 || (c->opt_timing == 1 && (c->energy_calls & 3ull) == 0ull);
     if (timed_call) hipEventRecord(c->ev_last, c->stream);

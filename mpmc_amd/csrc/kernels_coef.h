@@ -180,14 +180,76 @@ struct CoefFinish {
     SweepParams sp;
 };
 
+// Epilogue of a sweep for one wave = the 64 atoms of block t (s = the sums over all partners): the
+// bookkeeping of thole_iterative.c:186-252 (new mu, SOR/ESOR mix, RRMS, max-change) or the Palmo
+// contraction (:119-141), plus the block's share of the energy sums.
+template <int MODE>
+__device__ __forceinline__ void coef_epilogue(const CoefFinish &f, int t, int i, int lane, const double s[3], double al,
+                                              int fl, const double old[3], const double es[3], const double aux[3]) {
+    const bool valid = fl & kValid;
+    double e_i = 0.0, r_i = 0.0;
+    if ((MODE == kSweepJacobi && (al == 0.0 || !valid)) || (MODE == kSweepPalmo && !valid)) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            f.out[3 * i + p] = 0.0;
+            if (MODE == kSweepJacobi) f.ef_induced[3 * i + p] = 0.0;
+        }
+        if (MODE == kSweepJacobi && f.sp.want_rrms) f.rrms[i] = 0.0;
+    } else if (MODE == kSweepJacobi) {
+        double d2 = 0.0, n2 = 0.0, emax = 0.0, m[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const double e = -s[p];
+            const double nw = al * (es[p] + e);
+            f.ef_induced[3 * i + p] = e;
+            m[p] = f.sp.w_new * nw + f.sp.w_old * old[p];
+            f.out[3 * i + p] = m[p];
+            const double d = nw - old[p];
+            d2 += d * d;
+            n2 += nw * nw;
+            emax = fmax(emax, d * d);
+        }
+        if (f.sp.want_rrms) {
+            double rr = sqrt(d2 / n2);  // calc_dipole_rrms, thole_iterative.c:61-77
+            if (!isfinite(rr)) rr = 0.0;
+            f.rrms[i] = rr;
+            r_i = rr;
+        }
+        // are_we_done_yet (thole_iterative.c:104-113) needs max (new-old)^2: non-negative doubles order like
+        // their bit patterns, so an integer atomicMax is exact and order-independent.
+        atomicMax(f.errmax + f.sp.err_slot, (unsigned long long)__double_as_longlong(emax));
+        e_i = m[0] * es[0] + m[1] * es[1] + m[2] * es[2];
+    } else {
+        double m[3], dc[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            dc[p] = -aux[p] - s[p];
+            f.out[3 * i + p] = dc[p];
+            m[p] = old[p];
+        }
+        e_i = m[0] * es[0] + m[1] * es[1] + m[2] * es[2];
+        e_i += m[0] * dc[0] + m[1] * dc[1] + m[2] * dc[2];
+        const double rr = f.rrms[i];
+        r_i = isfinite(rr) ? rr : 0.0;
+    }
+    e_i = wave_sum(e_i);
+    r_i = wave_sum(r_i);
+    if (lane == 0) {
+        f.energy_part[2 * t] = e_i;
+        f.energy_part[2 * t + 1] = r_i;
+    }
+}
+
 // y_i = sum_{tj >= t} Srow[tj][block t] + sum_{ti < t} Zcol[ti][block t]  (nt terms, fixed order), then the
 // epilogue.  grid = nt; block = 1024 = 64 atoms x 16 term groups, combined through LDS.
 //
-// (Folding this into the sweep -- the last workgroup to feed a block finishes it, found through a
-// counter -- was tried and lost: the release/acquire it needs between workgroups on different XCDs
-// costs either a whole-L2 write-back + invalidate per workgroup (250 us per sweep) or, with
-// write-through stores and a returning atomic, ~3 us of exposed latency per workgroup (+15 us per
-// sweep), against ~7 us for this launch.)
+// (Folding this into the sweep was tried three ways and lost each time against the ~8.5 us this launch
+// costs, boundary included: (1) the last workgroup to feed a block finishes it, found through a counter
+// behind device-scope fences: a whole-L2 write-back + invalidate per workgroup, 250 us per sweep;
+// (2) the same with write-through stores and a returning atomic: ~3 us of exposed latency per workgroup,
+// +15 us per sweep; (3) the diagonal tiles' workgroups, dispatched last, poll the partials
+// data-is-the-flag style and finish their block: correct, but the finisher's serial tail (tile, L2-
+// bypassing polls, epilogue) made the launch 27 us instead of 17 + 8.5.)
 constexpr int kCoefFinishGroups = 16;
 template <int MODE>
 __global__ __launch_bounds__(64 * kCoefFinishGroups) void pair_finish_kernel(int nt, const double *__restrict__ Srow,
@@ -251,58 +313,7 @@ __global__ __launch_bounds__(64 * kCoefFinishGroups) void pair_finish_kernel(int
         for (int k = 0; k < kCoefFinishGroups; ++k) acc += part[k][p][lane];
         s[p] = acc;
     }
-    const bool valid = fl & kValid;
-    double e_i = 0.0, r_i = 0.0;
-    if ((MODE == kSweepJacobi && (al == 0.0 || !valid)) || (MODE == kSweepPalmo && !valid)) {
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            f.out[3 * i + p] = 0.0;
-            if (MODE == kSweepJacobi) f.ef_induced[3 * i + p] = 0.0;
-        }
-        if (MODE == kSweepJacobi && f.sp.want_rrms) f.rrms[i] = 0.0;
-    } else if (MODE == kSweepJacobi) {
-        double d2 = 0.0, n2 = 0.0, emax = 0.0, m[3];
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            const double e = -s[p];
-            const double nw = al * (es[p] + e);
-            f.ef_induced[3 * i + p] = e;
-            m[p] = f.sp.w_new * nw + f.sp.w_old * old[p];
-            f.out[3 * i + p] = m[p];
-            const double d = nw - old[p];
-            d2 += d * d;
-            n2 += nw * nw;
-            emax = fmax(emax, d * d);
-        }
-        if (f.sp.want_rrms) {
-            double rr = sqrt(d2 / n2);  // calc_dipole_rrms, thole_iterative.c:61-77
-            if (!isfinite(rr)) rr = 0.0;
-            f.rrms[i] = rr;
-            r_i = rr;
-        }
-        // are_we_done_yet (thole_iterative.c:104-113) needs max (new-old)^2: non-negative doubles order like
-        // their bit patterns, so an integer atomicMax is exact and order-independent.
-        atomicMax(f.errmax + f.sp.err_slot, (unsigned long long)__double_as_longlong(emax));
-        e_i = m[0] * es[0] + m[1] * es[1] + m[2] * es[2];
-    } else {
-        double m[3], dc[3];
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            dc[p] = -aux[p] - s[p];
-            f.out[3 * i + p] = dc[p];
-            m[p] = old[p];
-        }
-        e_i = m[0] * es[0] + m[1] * es[1] + m[2] * es[2];
-        e_i += m[0] * dc[0] + m[1] * dc[1] + m[2] * dc[2];
-        const double rr = f.rrms[i];
-        r_i = isfinite(rr) ? rr : 0.0;
-    }
-    e_i = wave_sum(e_i);
-    r_i = wave_sum(r_i);
-    if (lane == 0) {
-        f.energy_part[2 * t] = e_i;
-        f.energy_part[2 * t + 1] = r_i;
-    }
+    coef_epilogue<MODE>(f, t, i, lane, s, al, fl, old, es, aux);
 }
 
 template <int ORTHO>

@@ -320,17 +320,30 @@ __global__ __launch_bounds__(256) void ewald_self_kernel(DevAtoms a, double ewal
 }
 
 // Fixed-order sum of `count` rows of `channels` doubles each: out[c] = sum_r in[r][c].
-__global__ __launch_bounds__(256) void reduce_rows_kernel(const double *__restrict__ in, int count, int channels,
-                                                           double *__restrict__ out) {
-    __shared__ double s[4];
-    for (int c = 0; c < channels; ++c) {
-        double acc = 0.0;
-        for (int r = threadIdx.x; r < count; r += blockDim.x) acc += in[(size_t)r * channels + c];
-        acc = wave_sum(acc);
-        if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
-        __syncthreads();
-        if (threadIdx.x == 0) out[c] = (s[0] + s[1]) + (s[2] + s[3]);
-        __syncthreads();
+// out[c] = sum over rows of in[r][c] (channels <= 4), fixed order: thread t takes rows t, t + 1024, ...,
+// 64-lane butterflies, then the 16 wave sums in order.  One workgroup of kReduceThreads.
+constexpr int kReduceThreads = 1024;
+__global__ __launch_bounds__(kReduceThreads) void reduce_rows_kernel(const double *__restrict__ in, int count,
+                                                                      int channels, double *__restrict__ out) {
+    __shared__ double s[kReduceThreads / 64][4];
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int r = threadIdx.x; r < count; r += kReduceThreads) {
+        const double *p = in + (size_t)r * channels;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < channels) acc[c] += p[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        acc[c] = wave_sum(acc[c]);
+        if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6][c] = acc[c];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < channels) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < kReduceThreads / 64; ++w) t += s[w][threadIdx.x];
+        out[threadIdx.x] = t;
     }
 }
 
