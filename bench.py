@@ -118,6 +118,12 @@ def main():
     chain = host.HostSystem(system, flags, device=local_rank, seed=args.seed + rank)
     avg = WalkerAverages(dist=dist, device=dev)
     chain.energy()  # creates the device context, uploads the configuration
+    if os.environ.get("MPMC_OVERLAP"):
+        chain.energy()
+        chain.set_option("overlap_streams", int(os.environ["MPMC_OVERLAP"]))
+    if os.environ.get("MPMC_STEP_GRAPH"):
+        chain.energy()
+        chain.set_option("step_graph", int(os.environ["MPMC_STEP_GRAPH"]))
     if os.environ.get("MPMC_SYM_MODE"):
         chain.energy()
         chain.set_option("sym_mode", int(os.environ["MPMC_SYM_MODE"]))

@@ -97,6 +97,7 @@ typedef struct mpmc_hip_timings {
     float total_ms;       /* first launch to last kernel end             */
     int sweep_count;      /* number of sweep launches inside sweep_ms    */
     int amatrix_count;
+    int graph_steps;      /* energy() calls replayed as a HIP graph so far (option "step_graph") */
 } mpmc_hip_timings;
 
 const char *mpmc_hip_last_error(void);
@@ -143,6 +144,13 @@ int mpmc_hip_update_atoms(mpmc_hip_ctx *ctx, int first, int count, const double 
 
 /* One full energy() evaluation on the device. */
 int mpmc_hip_energy(mpmc_hip_ctx *ctx, mpmc_hip_result *out);
+
+/* The same in two halves: _begin enqueues the evaluation and returns, _end waits for it and fills the
+ * result.  The reference's energy() does host-side bookkeeping that does not depend on the energies
+ * (update_com(), countN(): pairs.c:331, energy.c:217); between the two calls that work overlaps the
+ * device.  No upload/update_atoms/set_box is accepted while an evaluation is in flight. */
+int mpmc_hip_energy_begin(mpmc_hip_ctx *ctx);
+int mpmc_hip_energy_end(mpmc_hip_ctx *ctx, mpmc_hip_result *out);
 
 /* Per-atom vectors of the last energy(): atom->mu, ef_static, ef_induced,
  * ef_induced_change, each [n][3] (needed by write_dipole/write_field at corrtime,

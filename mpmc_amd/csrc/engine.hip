@@ -20,6 +20,8 @@
 #include <cstdio>
 #include <cstring>
 #include <functional>
+#include <tuple>
+#include <utility>
 #include <ctime>
 #include <numeric>
 #include <string>
@@ -86,6 +88,7 @@ enum ResSlot {
     R_SELF = 6,
     R_UPOL = 7,
     R_RRMS = 8,
+    R_GS_ERR = 9,  // bit 0 / 1: the persistent Gauss-Seidel kernel of view 0 / 1 gave up on a hand-off
     R_RMIN = 9,
     R_COUNT = 16
 };
@@ -117,6 +120,25 @@ struct SweepView {
     double *Srow = nullptr, *Zcol = nullptr;  // partial sums of the symmetric sweep
     size_t symcap = 0;
     std::vector<int> h_idx;
+};
+
+// The kernels of one steady-state MC step whose arguments change from step to step; every other node of
+// the captured graph is replayed as it was.
+enum GraphSlotId { GS_MOVES = 0, GS_COEF, GS_FIELD, GS_PAIR, GS_PUBLISH, GS_NSLOT };
+enum GraphMode { GM_DIRECT = 0, GM_CAPTURE = 1, GM_UPDATE = 2 };
+struct StepGraph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    void *func[GS_NSLOT] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipGraphNode_t node[GS_NSLOT] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool valid = false;
+    unsigned long long rev = 0;  // config_rev it was captured under
+    // what the captured call left in the context besides device work
+    int iterations = 0;
+    struct SweepView *result_view = nullptr;
+    const double *result_mu = nullptr;
+    const double *energy_part = nullptr;
+    int energy_nt = 0;
 };
 
 struct mpmc_hip_ctx {
@@ -154,6 +176,18 @@ struct mpmc_hip_ctx {
     int field_key = -1;             // mode / chunking the resident field partials were made with
     double *d_lrcpart = nullptr;    // scratch of the (cached) long-range correction
     DirtyBlocks dirty_blocks;       // of the energy() call in progress
+    bool in_flight = false;         // between energy_begin() and energy_end()
+    // ---- one MC step as a HIP graph (see graph_step())
+    int opt_graph = 0;                   // "step_graph": off by default, see graph_step()
+    int graph_mode = 0;                  // GM_DIRECT | GM_CAPTURE | GM_UPDATE
+    StepGraph sg;
+    unsigned long long config_rev = 1;   // bumped by everything that changes what an energy() call enqueues
+    int eligible_streak = 0;             // consecutive calls that met graph_eligible()
+    bool staged_copies = false;          // coordinates reached the device outside the MoveList since the last call
+    unsigned long long graph_launches = 0;
+    double graph_update_s = 0.0, graph_launch_s = 0.0;
+    bool call_polar = false, call_timed = false;
+    int call_iterations = 0, call_iter_success = 0;
     std::function<void()> enqueue_side;  // set while run_polarization() may feed the side stream (see energy())
     double host_enqueue_s = 0.0, host_wait_s = 0.0;  // MPMC_HIP_HOST_PROFILE=1: printed at destroy
     bool box_ortho = false; // every off-diagonal basis entry is exactly zero
@@ -240,15 +274,48 @@ static DevBox dev_box(const mpmc_hip_ctx *c) {
 
 static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+// timing 1: events around the sweep kernels of every 8th call (an event pair costs ~4 us of stream time,
+// and a timed call is enqueued launch by launch instead of replaying the step graph); 2: every call
+static inline bool is_timed_call(const mpmc_hip_ctx *c) {
+    return c->opt_timing >= 2 || (c->opt_timing == 1 && (c->energy_calls & 7ull) == 0ull);
+}
+
+// Launch of one of the GraphSlotId kernels: a plain launch (which stream capture records), or, while a
+// step graph is being refreshed, an update of that kernel's node in the instantiated graph.
+template <typename... KArgs, typename... Args, size_t... I>
+static hipError_t launch_slot_impl(mpmc_hip_ctx *c, int slot, void (*kernel)(KArgs...), dim3 g, dim3 b, hipStream_t s,
+                                   std::index_sequence<I...>, Args &&...args) {
+    std::tuple<KArgs...> vals(std::forward<Args>(args)...);
+    void *argv[] = {(void *)&std::get<I>(vals)...};
+    if (c->graph_mode == GM_UPDATE) {
+        hipKernelNodeParams p;
+        memset(&p, 0, sizeof(p));
+        p.func = (void *)kernel;
+        p.gridDim = g;
+        p.blockDim = b;
+        p.sharedMemBytes = 0;
+        p.kernelParams = argv;
+        p.extra = nullptr;
+        return hipGraphExecKernelNodeSetParams(c->sg.exec, c->sg.node[slot], &p);
+    }
+    c->sg.func[slot] = (void *)kernel;
+    return hipLaunchKernel((const void *)kernel, g, b, argv, 0, s);
+}
+template <typename... KArgs, typename... Args>
+static hipError_t launch_slot(mpmc_hip_ctx *c, int slot, void (*kernel)(KArgs...), dim3 g, dim3 b, hipStream_t s,
+                              Args &&...args) {
+    static_assert(sizeof...(KArgs) == sizeof...(Args), "argument count");
+    return launch_slot_impl(c, slot, kernel, g, b, s, std::index_sequence_for<KArgs...>{}, std::forward<Args>(args)...);
+}
+
 struct ScopedTimer {
     mpmc_hip_ctx *c;
     hipStream_t s;
     TimeRec r;
     bool on;
     ScopedTimer(mpmc_hip_ctx *ctx, int cls, hipStream_t st = nullptr) : c(ctx), s(st ? st : ctx->stream), on(false) {
-        // timing 1: the sweep kernels of every 4th call (an event pair costs ~4 us of stream time)
-        const bool wanted = c->opt_timing >= 2 ||
-                            (c->opt_timing == 1 && cls == 4 /* T_SWEEP */ && (c->energy_calls & 3ull) == 0ull);
+        const bool wanted = c->graph_mode == GM_DIRECT &&
+                            (c->opt_timing >= 2 || (cls == 4 /* T_SWEEP */ && is_timed_call(c)));
         if (wanted && c->ev_next + 2 <= c->ev_pool.size()) {
             r.cls = cls;
             r.a = c->ev_pool[c->ev_next++];
@@ -267,6 +334,11 @@ struct ScopedTimer {
 
 extern "C" int mpmc_hip_set_option(mpmc_hip_ctx *c, const char *name, int value) {
     if (!c || !name) return fail("MPMC_HIP: set_option: null argument");
+    ++c->config_rev;
+    if (!strcmp(name, "step_graph")) {
+        c->opt_graph = value;
+        return 0;
+    }
     if (!strcmp(name, "incremental_amatrix")) {
         c->opt_incremental = value;
         c->all_dirty = true;
@@ -403,11 +475,17 @@ extern "C" int mpmc_hip_create(mpmc_hip_ctx **out, int device, int max_atoms) {
     return 0;
 }
 
+static void graph_destroy(mpmc_hip_ctx *c);
+
 extern "C" void mpmc_hip_destroy(mpmc_hip_ctx *c) {
     if (!c) return;
     if (getenv("MPMC_HIP_HOST_PROFILE") && c->energy_calls)
-        fprintf(stderr, "MPMC_HIP host profile: %llu energy() calls, enqueue %.1f us, wait %.1f us per call\n",
-                c->energy_calls, 1e6 * c->host_enqueue_s / c->energy_calls, 1e6 * c->host_wait_s / c->energy_calls);
+        fprintf(stderr, "MPMC_HIP host profile: %llu energy() calls (%llu as graph), enqueue %.1f us, wait %.1f us per call\n",
+                c->energy_calls, c->graph_launches, 1e6 * c->host_enqueue_s / c->energy_calls,
+                1e6 * c->host_wait_s / c->energy_calls);
+    if (getenv("MPMC_HIP_HOST_PROFILE") && c->graph_launches)
+        fprintf(stderr, "MPMC_HIP graph steps: node updates %.1f us, launch %.1f us per step\n",
+                1e6 * c->graph_update_s / c->graph_launches, 1e6 * c->graph_launch_s / c->graph_launches);
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->stream2) hipStreamSynchronize(c->stream2);
@@ -423,6 +501,7 @@ extern "C" void mpmc_hip_destroy(mpmc_hip_ctx *c) {
         for (void *p : vp)
             if (p) hipFree(p);
     }
+    graph_destroy(c);
     if (c->stream2) hipStreamDestroy(c->stream2);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
@@ -461,6 +540,7 @@ extern "C" int mpmc_hip_set_params(mpmc_hip_ctx *c, const mpmc_hip_params *p) {
     }
     if (p->polar_damp != c->par.polar_damp) c->all_dirty = true;
     c->pair_part_valid = c->field_part_valid = false;
+    ++c->config_rev;
     c->par = *p;
     c->have_params = true;
     c->kvecf_valid = false;
@@ -471,6 +551,7 @@ extern "C" int mpmc_hip_set_params(mpmc_hip_ctx *c, const mpmc_hip_params *p) {
 // reference src/energy/pbc.c:13-83
 extern "C" int mpmc_hip_set_box(mpmc_hip_ctx *c, const double basis[9], double pbc_cutoff) {
     if (!c || !basis) return fail("MPMC_HIP: set_box: null argument");
+    if (c->in_flight) return fail("MPMC_HIP: set_box between energy_begin() and energy_end()");
     double b[3][3];
     for (int p = 0; p < 3; ++p)
         for (int q = 0; q < 3; ++q) b[p][q] = basis[3 * p + q];
@@ -510,6 +591,7 @@ extern "C" int mpmc_hip_set_box(mpmc_hip_ctx *c, const double basis[9], double p
     c->cutoff = cutoff;
     c->volume = vol;
     c->have_box = true;
+    ++c->config_rev;
     c->box_ortho = (b[0][1] == 0.0 && b[0][2] == 0.0 && b[1][0] == 0.0 && b[1][2] == 0.0 && b[2][0] == 0.0 &&
                     b[2][1] == 0.0);
     c->kvecf_valid = false;
@@ -524,6 +606,7 @@ extern "C" int mpmc_hip_upload(mpmc_hip_ctx *c, int n, const double *x, const do
                                const double *sigma, const double *mass, const int *molecule,
                                const uint8_t *frozen) {
     if (!c) return fail("MPMC_HIP: upload: null context");
+    if (c->in_flight) return fail("MPMC_HIP: upload between energy_begin() and energy_end()");
     if (n <= 0 || n > c->max_atoms) return fail("MPMC_HIP: upload: n = %d outside (0, %d]", n, c->max_atoms);
     if (!x || !y || !z || !charge || !polarizability || !epsilon || !sigma || !mass || !molecule || !frozen)
         return fail("MPMC_HIP: upload: null array");
@@ -593,6 +676,7 @@ extern "C" int mpmc_hip_upload(mpmc_hip_ctx *c, int n, const double *x, const do
     c->view[0].A_valid = c->view[1].A_valid = false;
     c->view[0].C_valid = c->view[1].C_valid = false;
     c->view[0].pos_valid = c->view[1].pos_valid = false;
+    ++c->config_rev;
     if (v0.nv > 0) HIPCHK(hipMemcpy(v0.d_idx, v0.h_idx.data(), v0.nv * sizeof(int), hipMemcpyHostToDevice));
     return 0;
 }
@@ -601,8 +685,8 @@ extern "C" int mpmc_hip_upload(mpmc_hip_ctx *c, int n, const double *x, const do
 static int flush_moves(mpmc_hip_ctx *c) {
     if (c->pending.n > 0) {
         SweepView &v0 = c->view[0];
-        hipLaunchKernelGGL(apply_moves_kernel, dim3(1), dim3(64), 0, c->stream, c->pending, c->d_x, c->d_y, c->d_z,
-                           v0.d_slot, v0.px, v0.py, v0.pz);
+        HIPCHK(launch_slot(c, GS_MOVES, apply_moves_kernel, dim3(1), dim3(64), c->stream, c->pending, c->d_x, c->d_y,
+                           c->d_z, v0.d_slot, v0.px, v0.py, v0.pz));
         c->pending.n = 0;
     }
     return 0;
@@ -611,6 +695,7 @@ static int flush_moves(mpmc_hip_ctx *c) {
 extern "C" int mpmc_hip_update_atoms(mpmc_hip_ctx *c, int first, int count, const double *x, const double *y,
                                      const double *z) {
     if (!c || !c->have_atoms) return fail("MPMC_HIP: update_atoms: no configuration uploaded");
+    if (c->in_flight) return fail("MPMC_HIP: update_atoms between energy_begin() and energy_end()");
     if (first < 0 || count <= 0 || first + count > c->n)
         return fail("MPMC_HIP: update_atoms: range [%d, %d) outside [0, %d)", first, first + count, c->n);
     if (!x || !y || !z) return fail("MPMC_HIP: update_atoms: null array");
@@ -644,6 +729,7 @@ extern "C" int mpmc_hip_update_atoms(mpmc_hip_ctx *c, int first, int count, cons
         // nothing to launch yet
     } else if ((size_t)(3 * count) <= c->stage_cap) {
         if (flush_moves(c)) return -1;
+        c->staged_copies = true;
         c->view[0].pos_valid = false;
         // small delta (one molecule): stage in pinned memory so the copies are truly asynchronous and the
         // caller's buffers are free at once; the ring is recycled after the next energy() has synchronised
@@ -661,6 +747,7 @@ extern "C" int mpmc_hip_update_atoms(mpmc_hip_ctx *c, int first, int count, cons
         HIPCHK(hipMemcpyAsync(c->d_z + first, s + 2 * count, b, hipMemcpyHostToDevice, c->stream));
     } else {
         if (flush_moves(c)) return -1;
+        c->staged_copies = true;
         c->view[0].pos_valid = false;
         HIPCHK(hipMemcpyAsync(c->d_x + first, x, b, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(c->d_y + first, y, b, hipMemcpyHostToDevice, c->stream));
@@ -827,7 +914,10 @@ static int ensure_static_field(mpmc_hip_ctx *c) {
 // the 16-double result record goes straight into mapped pinned host memory (no copy engine / copy kernel)
 // followed by a sequence number the host spins on (no dependence on the device's sync-scheduling mode)
 __global__ void publish_result_kernel(double *__restrict__ d_res, volatile double *__restrict__ h_res, int n,
-                                      double seq, const double *__restrict__ energy_part, int nt, int n_total) {
+                                      double seq, const double *__restrict__ energy_part, int nt, int n_total,
+                                      const unsigned *__restrict__ gs_err0, const unsigned *__restrict__ gs_err1) {
+    // error words of the persistent Gauss-Seidel launches of this call travel with the result record
+    if (threadIdx.x == 0) d_res[R_GS_ERR] = ((gs_err0 && *gs_err0) ? 1.0 : 0.0) + ((gs_err1 && *gs_err1) ? 2.0 : 0.0);
     if (nt > 0) {
         // U_pol and <rrms> from the per-block sums the finish step left (fixed order)
         double e = 0.0, r = 0.0;
@@ -848,33 +938,43 @@ __global__ void publish_result_kernel(double *__restrict__ d_res, volatile doubl
     if (threadIdx.x == 0) h_res[n] = seq;
 }
 
-extern "C" int mpmc_hip_energy(mpmc_hip_ctx *c, mpmc_hip_result *out) {
-    if (!c || !out) return fail("MPMC_HIP: energy: null argument");
-    if (!c->have_atoms) return fail("MPMC_HIP: energy: no configuration uploaded");
-    if (!c->have_box) return fail("MPMC_HIP: energy: no box set");
-    HIPCHK(hipSetDevice(c->device));
+// LJ / real-space Ewald tile kernel (graph slot GS_PAIR).  Tile partials persist: after a single-molecule
+// move only the tiles of the moved atoms' blocks are recomputed.
+static int launch_pair_kernel(mpmc_hip_ctx *c, const DevAtoms &a, const DevBox &bx, hipStream_t sb) {
     const mpmc_hip_params &P = c->par;
-    c->ewald_alpha = P.ewald_alpha_set ? P.ewald_alpha : 3.5 / c->cutoff;                    // pbc.c:73-74
-    c->polar_ewald_alpha = P.polar_ewald_alpha_set ? P.polar_ewald_alpha : 3.5 / c->cutoff;  // pbc.c:75-76
-    if (!P.rd_only && !P.wolf && (!c->kvec_valid || c->kvec_kmax != P.ewald_kmax)) {
-        if (build_kvectors(c)) return -1;
-        c->kvec_kmax = P.ewald_kmax;
-    }
-    memset(out, 0, sizeof(*out));
-    c->ev_next = 0;
-    c->recs.clear();
-    ++c->energy_calls;
-    timespec ts0, ts1, ts2;
-    clock_gettime(CLOCK_MONOTONIC, &ts0);
-    if (flush_moves(c)) return -1;
-    if (c->opt_timing >= 2 || (c->opt_timing == 1 && (c->energy_calls & 3ull) == 0ull))
-        hipEventRecord(c->ev_first, c->stream);
-
-    const DevAtoms a = dev_atoms(c);
-    const DevBox bx = dev_box(c);
     const int ntile = c->npad / 64;
-    int polar_iterations = 0, iter_success = 0;
-    // 64-atom blocks touched by the moves since the last call (n = 0: recompute every tile)
+    PairParams pp;
+    pp.ewald_alpha = c->ewald_alpha;
+    pp.temperature = P.temperature;
+    pp.rd_only = P.rd_only;
+    pp.fh_order = P.feynman_hibbs ? P.feynman_hibbs_order : 0;
+    pp.wolf = P.wolf;
+    pp.erfaRoverR = std::erf(c->ewald_alpha * c->cutoff) / c->cutoff;
+    DirtyBlocks sel = c->dirty_blocks;
+    if (!c->pair_part_valid) sel.n = 0;
+    const dim3 grid(ntile, sel.n > 0 ? sel.n : ntile), block(64 * kPairWaves);
+    if (c->pair_part_valid && c->dirty_atoms.empty()) return 0;  // nothing moved since the partials were made
+    if (pp.fh_order == 0)
+        HIPCHK(launch_slot(c, GS_PAIR, pair_rd_es_kernel<0>, grid, block, sb, a, bx, pp, sel, c->d_pairpart));
+    else if (pp.fh_order == 2)
+        HIPCHK(launch_slot(c, GS_PAIR, pair_rd_es_kernel<2>, grid, block, sb, a, bx, pp, sel, c->d_pairpart));
+    else
+        HIPCHK(launch_slot(c, GS_PAIR, pair_rd_es_kernel<4>, grid, block, sb, a, bx, pp, sel, c->d_pairpart));
+    c->pair_part_valid = true;
+    return 0;
+}
+
+static int launch_publish(mpmc_hip_ctx *c, bool do_polar) {
+    HIPCHK(launch_slot(c, GS_PUBLISH, publish_result_kernel, dim3(1), dim3(64), c->stream, c->d_res, c->h_res_dev,
+                       (int)R_COUNT, (double)c->energy_calls, do_polar ? c->energy_part : (const double *)nullptr,
+                       do_polar ? c->energy_nt : 0, c->n,
+                       c->gs_used[0] ? (const unsigned *)(c->view[0].gsflags + 1) : (const unsigned *)nullptr,
+                       c->gs_used[1] ? (const unsigned *)(c->view[1].gsflags + 1) : (const unsigned *)nullptr));
+    return 0;
+}
+
+// 64-atom blocks touched by the moves since the last call (n = 0: recompute every tile)
+static void collect_dirty_blocks(mpmc_hip_ctx *c) {
     DirtyBlocks dirty_blocks;
     dirty_blocks.n = 0;
     if (c->all_dirty || !c->opt_incremental_pairs) {
@@ -895,6 +995,18 @@ extern "C" int mpmc_hip_energy(mpmc_hip_ctx *c, mpmc_hip_result *out) {
     }
     for (int k = dirty_blocks.n; k < kMaxDirtyBlocks; ++k) dirty_blocks.blk[k] = 0;
     c->dirty_blocks = dirty_blocks;
+}
+
+// One evaluation, launch by launch (also what stream capture records for the step graph).
+static int enqueue_direct(mpmc_hip_ctx *c) {
+    if (flush_moves(c)) return -1;
+    if (is_timed_call(c)) hipEventRecord(c->ev_first, c->stream);
+
+    const DevAtoms a = dev_atoms(c);
+    const DevBox bx = dev_box(c);
+    const int ntile = c->npad / 64;
+    int polar_iterations = 0, iter_success = 0;
+    const mpmc_hip_params &P = c->par;
 
     // ---- fork: LJ / Ewald kernels (fp64-VALU bound) run on stream2 while the polarization chain
     // (HBM bound) runs on the main stream -- the device-side analogue of the reference starting its
@@ -934,26 +1046,7 @@ extern "C" int mpmc_hip_energy(mpmc_hip_ctx *c, mpmc_hip_result *out) {
         // ---- fused pair kernel: LJ(+FH) and real-space Ewald(+FH, + intra-molecular screening)
         {
             ScopedTimer t(c, T_PAIR, sb);
-            PairParams pp;
-            pp.ewald_alpha = c->ewald_alpha;
-            pp.temperature = P.temperature;
-            pp.rd_only = P.rd_only;
-            pp.fh_order = P.feynman_hibbs ? P.feynman_hibbs_order : 0;
-            pp.wolf = P.wolf;
-            pp.erfaRoverR = std::erf(c->ewald_alpha * c->cutoff) / c->cutoff;
-            // tile partials persist: after a single-molecule move only the tiles of the moved atoms' blocks
-            DirtyBlocks sel = dirty_blocks;
-            if (!c->pair_part_valid) sel.n = 0;
-            const dim3 grid(ntile, sel.n > 0 ? sel.n : ntile), block(64 * kPairWaves);
-            if (c->pair_part_valid && c->dirty_atoms.empty())
-                ;  // nothing moved since the partials were made
-            else if (pp.fh_order == 0)
-                hipLaunchKernelGGL(pair_rd_es_kernel<0>, grid, block, 0, sb, a, bx, pp, sel, c->d_pairpart);
-            else if (pp.fh_order == 2)
-                hipLaunchKernelGGL(pair_rd_es_kernel<2>, grid, block, 0, sb, a, bx, pp, sel, c->d_pairpart);
-            else
-                hipLaunchKernelGGL(pair_rd_es_kernel<4>, grid, block, 0, sb, a, bx, pp, sel, c->d_pairpart);
-            c->pair_part_valid = true;
+            if (launch_pair_kernel(c, a, bx, sb)) return -1;
             hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(kReduceThreads), 0, sb, c->d_pairpart, ntile * ntile,
                                kPairChannels, c->d_res + R_RD_PAIR);
         }
@@ -995,15 +1088,197 @@ extern "C" int mpmc_hip_energy(mpmc_hip_ctx *c, mpmc_hip_result *out) {
     enqueue_side();
     if (side_rc) return -1;
     if (c->opt_overlap) hipStreamWaitEvent(c->stream, c->ev_join, 0);
-    const bool timed_call = c->opt_timing >= 2 || (c->opt_timing == 1 && (c->energy_calls & 3ull) == 0ull);
+    const bool timed_call = is_timed_call(c);
     if (timed_call) hipEventRecord(c->ev_last, c->stream);
-    hipLaunchKernelGGL(publish_result_kernel, dim3(1), dim3(64), 0, c->stream, c->d_res, c->h_res_dev, (int)R_COUNT,
-                       (double)c->energy_calls, do_polar ? c->energy_part : nullptr, do_polar ? c->energy_nt : 0, c->n);
-    c->h_gserr[0] = c->h_gserr[1] = 0;
-    for (int v = 0; v < 2; ++v)
-        if (c->gs_used[v])
-            HIPCHK(hipMemcpyAsync(c->h_gserr + v, c->view[v].gsflags + 1, sizeof(unsigned), hipMemcpyDeviceToHost,
-                                  c->stream));
+    if (launch_publish(c, do_polar)) return -1;
+    c->call_polar = do_polar;
+    c->call_iterations = polar_iterations;
+    c->call_iter_success = iter_success;
+    c->call_timed = timed_call;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// A steady-state MC step (one molecule displaced, everything resident, fixed iteration count) always
+// enqueues the same ~25 kernels; only five of them see new arguments (GraphSlotId).  With option
+// "step_graph" such a step is captured once into a HIP graph and afterwards replayed with one launch
+// after refreshing those five nodes; anything else (uploads, parameter changes, timed calls,
+// Gauss-Seidel / precision-controlled solves, moves that miss the incremental paths) goes launch by
+// launch.  Results are bit-identical.  OFF by default -- measured on MI355X / ROCm 7.2 (4096-atom box):
+// refreshing the five nodes costs 3 us, but hipGraphLaunch of the two-stream graph costs 60 us of host
+// time and the replay finishes later than 22 direct launches (237 vs 152 us per energy()); captured on
+// one stream the launch drops to 15 us, but the LJ/Ewald kernels no longer overlap the sweeps (183 us).
+// ---------------------------------------------------------------------------------------------
+static bool graph_eligible(mpmc_hip_ctx *c) {
+    const mpmc_hip_params &P = c->par;
+    const SweepView &v = c->view[0];
+    if (!c->opt_graph || is_timed_call(c) || !c->opt_incremental || !c->opt_incremental_pairs ||
+        !c->opt_pair_coef)
+        return false;
+    if (P.rd_only || !P.polarization || P.polar_zodid || P.polar_gs || P.polar_gs_ranked || P.polar_precision != 0.0 ||
+        P.polar_max_iter <= 0)
+        return false;
+    if (c->all_dirty || c->staged_copies || c->pending.n <= 0 || c->dirty_blocks.n < 1) return false;
+    if (!v.C_valid || !v.pos_valid || !c->pair_part_valid || !c->field_part_valid) return false;
+    if (P.rd_lrc && !c->lrc_valid) return false;
+    if (P.polar_ewald && !c->kvecf_valid) return false;
+    bool polarizable_moved = false;
+    for (int atom : c->dirty_atoms) polarizable_moved |= (v.slot_of_atom[atom] >= 0);
+    if (!polarizable_moved || c->dirty_atoms.size() > (size_t)kMaxDirty) return false;
+    return true;
+}
+
+static void graph_destroy(mpmc_hip_ctx *c) {
+    if (c->sg.exec) hipGraphExecDestroy(c->sg.exec);
+    if (c->sg.graph) hipGraphDestroy(c->sg.graph);
+    c->sg = StepGraph();
+}
+
+// after a capture: instantiate and find the five nodes that get new arguments every step
+static bool graph_finish_capture(mpmc_hip_ctx *c, hipGraph_t graph) {
+    StepGraph &g = c->sg;
+    g.graph = graph;
+    if (hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0) != hipSuccess) return false;
+    size_t nn = 0;
+    if (hipGraphGetNodes(g.graph, nullptr, &nn) != hipSuccess || nn == 0) return false;
+    std::vector<hipGraphNode_t> nodes(nn);
+    if (hipGraphGetNodes(g.graph, nodes.data(), &nn) != hipSuccess) return false;
+    int found[GS_NSLOT] = {0, 0, 0, 0, 0};
+    for (hipGraphNode_t nd : nodes) {
+        hipGraphNodeType ty;
+        if (hipGraphNodeGetType(nd, &ty) != hipSuccess || ty != hipGraphNodeTypeKernel) continue;
+        hipKernelNodeParams p;
+        if (hipGraphKernelNodeGetParams(nd, &p) != hipSuccess) return false;
+        for (int s = 0; s < GS_NSLOT; ++s)
+            if (g.func[s] && p.func == g.func[s]) {
+                g.node[s] = nd;
+                found[s]++;
+            }
+    }
+    for (int s = 0; s < GS_NSLOT; ++s)
+        if (found[s] != 1) return false;
+    return true;
+}
+
+// replay: refresh the five nodes, launch
+static int graph_step(mpmc_hip_ctx *c) {
+    const DevAtoms a = dev_atoms(c);
+    const DevBox bx = dev_box(c);
+    timespec g0, g1, g2;
+    clock_gettime(CLOCK_MONOTONIC, &g0);
+    c->graph_mode = GM_UPDATE;
+    int rc = flush_moves(c);
+    if (!rc) rc = setup_view(c, c->view[0], a, bx, true, true);
+    if (!rc) rc = launch_field(c, a, bx);
+    if (!rc) rc = launch_pair_kernel(c, a, bx, c->stream2);
+    c->energy_part = c->sg.energy_part;
+    c->energy_nt = c->sg.energy_nt;
+    if (!rc) rc = launch_publish(c, true);
+    c->graph_mode = GM_DIRECT;
+    if (rc) return -1;
+    clock_gettime(CLOCK_MONOTONIC, &g1);
+    HIPCHK(hipGraphLaunch(c->sg.exec, c->stream));
+    clock_gettime(CLOCK_MONOTONIC, &g2);
+    c->graph_update_s += (g1.tv_sec - g0.tv_sec) + 1e-9 * (g1.tv_nsec - g0.tv_nsec);
+    c->graph_launch_s += (g2.tv_sec - g1.tv_sec) + 1e-9 * (g2.tv_nsec - g1.tv_nsec);
+    c->result_view = c->sg.result_view;
+    c->result_mu = c->sg.result_mu;
+    c->results_scattered = false;
+    c->have_polar_result = true;
+    c->call_polar = true;
+    c->call_iterations = c->sg.iterations;
+    c->call_iter_success = 0;
+    c->call_timed = false;
+    ++c->graph_launches;
+    return 0;
+}
+
+extern "C" int mpmc_hip_energy(mpmc_hip_ctx *c, mpmc_hip_result *out) {
+    if (mpmc_hip_energy_begin(c)) return -1;
+    return mpmc_hip_energy_end(c, out);
+}
+
+// Enqueue the whole evaluation; nothing waits for the device (except the per-iteration convergence test
+// of polar_precision mode), so the caller can do host work before mpmc_hip_energy_end() collects it.
+extern "C" int mpmc_hip_energy_begin(mpmc_hip_ctx *c) {
+    if (!c) return fail("MPMC_HIP: energy: null argument");
+    if (c->in_flight) return fail("MPMC_HIP: energy_begin: the previous evaluation has not been collected");
+    if (!c->have_atoms) return fail("MPMC_HIP: energy: no configuration uploaded");
+    if (!c->have_box) return fail("MPMC_HIP: energy: no box set");
+    HIPCHK(hipSetDevice(c->device));
+    const mpmc_hip_params &P = c->par;
+    c->ewald_alpha = P.ewald_alpha_set ? P.ewald_alpha : 3.5 / c->cutoff;                    // pbc.c:73-74
+    c->polar_ewald_alpha = P.polar_ewald_alpha_set ? P.polar_ewald_alpha : 3.5 / c->cutoff;  // pbc.c:75-76
+    if (!P.rd_only && !P.wolf && (!c->kvec_valid || c->kvec_kmax != P.ewald_kmax)) {
+        if (build_kvectors(c)) return -1;
+        c->kvec_kmax = P.ewald_kmax;
+    }
+    c->ev_next = 0;
+    c->recs.clear();
+    ++c->energy_calls;
+    timespec ts0, ts1;
+    clock_gettime(CLOCK_MONOTONIC, &ts0);
+    collect_dirty_blocks(c);
+    bool issued = false;
+    if (graph_eligible(c)) {
+        if (c->sg.valid && c->sg.rev == c->config_rev) {
+            if (graph_step(c)) return -1;
+            issued = true;
+        } else if (++c->eligible_streak >= 3) {
+            // third steady-state step in a row: record this one
+            graph_destroy(c);
+            const MoveList saved = c->pending;
+            bool ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+            if (ok) {
+                c->graph_mode = GM_CAPTURE;
+                const int rc = enqueue_direct(c);
+                c->graph_mode = GM_DIRECT;
+                hipGraph_t graph = nullptr;
+                ok = (hipStreamEndCapture(c->stream, &graph) == hipSuccess) && rc == 0 && graph != nullptr;
+                if (ok) ok = graph_finish_capture(c, graph);
+                else if (graph) hipGraphDestroy(graph);
+            }
+            if (ok) {
+                c->sg.valid = true;
+                c->sg.rev = c->config_rev;
+                c->sg.iterations = c->call_iterations;
+                c->sg.result_view = c->result_view;
+                c->sg.result_mu = c->result_mu;
+                c->sg.energy_part = c->energy_part;
+                c->sg.energy_nt = c->energy_nt;
+                HIPCHK(hipGraphLaunch(c->sg.exec, c->stream));
+                ++c->graph_launches;
+                issued = true;
+            } else {
+                // could not record: keep working launch by launch
+                (void)hipGetLastError();
+                graph_destroy(c);
+                c->opt_graph = 0;
+                c->pending = saved;
+            }
+        }
+    } else {
+        c->eligible_streak = 0;
+    }
+    if (!issued && enqueue_direct(c)) return -1;
+    c->staged_copies = false;
+    clock_gettime(CLOCK_MONOTONIC, &ts1);
+    c->host_enqueue_s += (ts1.tv_sec - ts0.tv_sec) + 1e-9 * (ts1.tv_nsec - ts0.tv_nsec);
+    c->dirty_atoms.clear();
+    c->all_dirty = false;
+    c->in_flight = true;
+    return 0;
+}
+
+extern "C" int mpmc_hip_energy_end(mpmc_hip_ctx *c, mpmc_hip_result *out) {
+    if (!c || !out) return fail("MPMC_HIP: energy: null argument");
+    if (!c->in_flight) return fail("MPMC_HIP: energy_end: no evaluation in flight");
+    c->in_flight = false;
+    memset(out, 0, sizeof(*out));
+    const mpmc_hip_params &P = c->par;
+    const bool do_polar = c->call_polar, timed_call = c->call_timed;
+    const int polar_iterations = c->call_iterations, iter_success = c->call_iter_success;
+    timespec ts1, ts2;
     clock_gettime(CLOCK_MONOTONIC, &ts1);
     {
         // spin on the sequence number the publish kernel writes last; fall back to a stream sync if it
@@ -1022,9 +1297,11 @@ extern "C" int mpmc_hip_energy(mpmc_hip_ctx *c, mpmc_hip_result *out) {
         if (!seen) HIPCHK(hipStreamSynchronize(c->stream));
     }
     clock_gettime(CLOCK_MONOTONIC, &ts2);
-    c->host_enqueue_s += (ts1.tv_sec - ts0.tv_sec) + 1e-9 * (ts1.tv_nsec - ts0.tv_nsec);
     c->host_wait_s += (ts2.tv_sec - ts1.tv_sec) + 1e-9 * (ts2.tv_nsec - ts1.tv_nsec);
-    const bool gs_timeout = (c->h_gserr[0] | c->h_gserr[1]) != 0;
+    const int gs_err = (int)c->h_res[R_GS_ERR];
+    c->h_gserr[0] = gs_err & 1;
+    c->h_gserr[1] = (gs_err >> 1) & 1;
+    const bool gs_timeout = gs_err != 0;
     c->gs_used[0] = c->gs_used[1] = false;
     if (gs_timeout) {
         unsigned dbg[8] = {0};
@@ -1037,8 +1314,6 @@ extern "C" int mpmc_hip_energy(mpmc_hip_ctx *c, mpmc_hip_result *out) {
     }
     HIPCHK(hipGetLastError());
     c->timed = timed_call;
-    c->dirty_atoms.clear();
-    c->all_dirty = false;
     c->stage_used = 0;
 
     const double *r = c->h_res;
@@ -1120,6 +1395,7 @@ extern "C" int mpmc_hip_download_ranking(mpmc_hip_ctx *c, double *rank_metric, i
 extern "C" int mpmc_hip_get_timings(mpmc_hip_ctx *c, mpmc_hip_timings *t) {
     if (!c || !t) return fail("MPMC_HIP: get_timings: null argument");
     memset(t, 0, sizeof(*t));
+    t->graph_steps = (int)c->graph_launches;
     if (!c->timed) return 0;
     HIPCHK(hipSetDevice(c->device));
     float acc[T_NCLASS] = {0};

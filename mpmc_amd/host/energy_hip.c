@@ -128,14 +128,23 @@ static int full_upload(system_t *system) {
 /* send only what changed since the previous call: one short range per moved molecule (after a rejected
  * move two molecules differ from the device copy -- the restored one and the newly displaced one -- and
  * they can be far apart in the list, so changed atoms are grouped into separate ranges) */
+/* One walk over the molecule lists: counts the atoms (reference countNatoms(), energy.c:36-46) and, while
+ * they still fit the shadow arrays, collects their coordinates for the comparison in delta_upload(). */
+static int collect_positions(system_t *system) {
+    shadow_t *sh = &g_shadow;
+    int i = 0;
+    for (molecule_t *m = system->molecules; m; m = m->next)
+        for (atom_t *a = m->atoms; a; a = a->next, i++)
+            if (i < sh->cap) {
+                sh->tx[i] = a->pos[0]; sh->ty[i] = a->pos[1]; sh->tz[i] = a->pos[2];
+            }
+    return i;
+}
+
 static int delta_upload(system_t *system) {
     shadow_t *sh = &g_shadow;
     const int n = system->natoms;
-    int i = 0;
-    for (molecule_t *m = system->molecules; m; m = m->next)
-        for (atom_t *a = m->atoms; a; a = a->next, i++) {
-            sh->tx[i] = a->pos[0]; sh->ty[i] = a->pos[1]; sh->tz[i] = a->pos[2];
-        }
+    int i;
     int lo = -1, hi = -1; /* current open range */
     for (i = 0; i <= n; i++) {
         const int changed = (i < n) && (sh->tx[i] != sh->x[i] || sh->ty[i] != sh->y[i] || sh->tz[i] != sh->z[i]);
@@ -159,7 +168,7 @@ static int delta_upload(system_t *system) {
 
 /* returns the total potential energy for the system and updates our observables */
 double energy(system_t *system) {
-    system->natoms = countNatoms(system);
+    system->natoms = collect_positions(system);
     if (system->hip_ctx && system->natoms > system->hip_capacity) { /* uvt grew past the context */
         mpmc_hip_destroy(system->hip_ctx);
         system->hip_ctx = NULL;
@@ -180,8 +189,15 @@ double energy(system_t *system) {
     } else if (delta_upload(system))
         return NAN;
 
+    /* the device works while the host does the bookkeeping that does not need the energies */
     mpmc_hip_result r;
-    if (mpmc_hip_energy(system->hip_ctx, &r)) {
+    if (mpmc_hip_energy_begin(system->hip_ctx)) {
+        hip_fail("energy");
+        return NAN;
+    }
+    update_com(system->molecules); /* pairs.c:331 */
+    countN(system);
+    if (mpmc_hip_energy_end(system->hip_ctx, &r)) {
         hip_fail("energy");
         return NAN;
     }
@@ -204,8 +220,6 @@ double energy(system_t *system) {
     system->nodestats->polarization_iterations = (double)r.polar_iterations;
     if (r.iter_success) system->iter_success = 1; /* thole_iterative.c:207; mc.c:347 resets it */
 
-    update_com(system->molecules); /* pairs.c:331 */
-    countN(system);
     o->NU = o->N * o->energy;          /* energy.c:219 */
     system->last_volume = system->pbc->volume; /* energy.c:222 */
     return o->energy;

@@ -307,6 +307,48 @@ def test_incremental_updates_are_bit_identical_to_full_recomputation(pair_coeffi
         e.close()
 
 
+def test_step_graph_replay_is_bit_identical_to_direct_launches():
+    """Option step_graph: a steady-state MC step is captured once as a HIP graph and replayed with only
+    the moved-atom arguments refreshed.  Same kernels, same order of every sum: energies must equal the
+    launch-by-launch path bit for bit over a chain of accepted and rejected moves."""
+    s = load("socmof_bssp_1228")
+    p = dict(FX["socmof_bssp_1228"]["params"])
+    p["polar_max_iter"] = 4
+    rng = np.random.default_rng(11)
+    engs = []
+    for graph in (1, 0):
+        e = engine.Engine(1228)
+        e.load_system(s, p)
+        e.set_option("timing", 0)
+        e.set_option("step_graph", graph)
+        engs.append(e)
+    pos = s["pos"].copy()
+    hist = [[], []]
+    for step in range(16):
+        first = 448 + 5 * int(rng.integers(0, (1228 - 448) // 5))
+        new = pos[first:first + 5] + rng.normal(scale=0.2, size=3)
+        accept = step % 3 != 2
+        for k, e in enumerate(engs):
+            e.update_atoms(first, new)
+            hist[k].append(e.energy())
+            if not accept:
+                e.update_atoms(first, pos[first:first + 5])
+        if accept:
+            pos[first:first + 5] = new
+    assert engs[0].timings()["graph_steps"] >= 10 and engs[1].timings()["graph_steps"] == 0
+    for a, b in zip(*hist):
+        for key in ("energy", "polarization_energy", "rd_energy", "coulombic_energy", "dipole_rrms"):
+            assert a[key] == b[key], key
+    s2 = dict(s)
+    s2["pos"] = pos
+    want = oracle.energy(s2, p, want_vectors=True)
+    for e in engs:
+        check_energies(e.energy(), want)
+        d = e.dipoles()
+        assert np.abs(d["mu"] - want["mu"]).max() <= 1e-10 * np.abs(want["mu"]).max()
+        e.close()
+
+
 def test_sweep_variants_agree():
     """The default sweep runs on pair coefficients (c3, c5 per pair, geometry rebuilt in registers); with
     pair_coefficients=0 it streams the expanded A matrix, either its upper triangle (each element used for
