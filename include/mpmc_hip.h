@@ -98,6 +98,8 @@ typedef struct mpmc_hip_timings {
     int sweep_count;      /* number of sweep launches inside sweep_ms    */
     int amatrix_count;
     int graph_steps;      /* energy() calls replayed as a HIP graph so far (option "step_graph") */
+    float event_pair_ms;  /* calibration: summed elapsed time of EMPTY event pairs (two records, nothing  */
+    int event_pair_count; /* between): what an event pair adds to the kernel it brackets               */
 } mpmc_hip_timings;
 
 const char *mpmc_hip_last_error(void);

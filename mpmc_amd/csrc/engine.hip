@@ -72,7 +72,7 @@ extern "C" int mpmc_hip_device_count(void) {
 // ------------------------------------------------------------------------------------------
 constexpr int kMaxDirty = 64;  // more moved atoms than this => full A rebuild (= DirtyList capacity)
 
-enum TimeClass { T_PAIR = 0, T_RECIP, T_FIELD, T_AMAT, T_SWEEP, T_PALMO, T_OTHER, T_NCLASS };
+enum TimeClass { T_PAIR = 0, T_RECIP, T_FIELD, T_AMAT, T_SWEEP, T_PALMO, T_OTHER, T_EVPAIR, T_NCLASS };
 
 struct TimeRec {
     int cls;
@@ -315,7 +315,7 @@ struct ScopedTimer {
     bool on;
     ScopedTimer(mpmc_hip_ctx *ctx, int cls, hipStream_t st = nullptr) : c(ctx), s(st ? st : ctx->stream), on(false) {
         const bool wanted = c->graph_mode == GM_DIRECT &&
-                            (c->opt_timing >= 2 || (cls == 4 /* T_SWEEP */ && is_timed_call(c)));
+                            (c->opt_timing >= 2 || ((cls == T_SWEEP || cls == T_EVPAIR) && is_timed_call(c)));
         if (wanted && c->ev_next + 2 <= c->ev_pool.size()) {
             r.cls = cls;
             r.a = c->ev_pool[c->ev_next++];
@@ -1416,6 +1416,8 @@ extern "C" int mpmc_hip_get_timings(mpmc_hip_ctx *c, mpmc_hip_timings *t) {
     t->other_ms = acc[T_OTHER];
     t->sweep_count = cnt[T_SWEEP];
     t->amatrix_count = cnt[T_AMAT];
+    t->event_pair_ms = acc[T_EVPAIR];
+    t->event_pair_count = cnt[T_EVPAIR];
     float tot = 0.f;
     HIPCHK(hipEventElapsedTime(&tot, c->ev_first, c->ev_last));
     t->total_ms = tot;

@@ -88,6 +88,8 @@ class Timings(C.Structure):
         ("sweep_count", C.c_int),
         ("amatrix_count", C.c_int),
         ("graph_steps", C.c_int),
+        ("event_pair_ms", C.c_float),
+        ("event_pair_count", C.c_int),
     ]
 
 

@@ -209,6 +209,7 @@ double energy(system_t *system) {
             s->amatrix_ms += t.amatrix_ms; s->sweep_ms += t.sweep_ms; s->palmo_ms += t.palmo_ms;
             s->other_ms += t.other_ms; s->total_ms += t.total_ms;
             s->sweep_count += t.sweep_count; s->amatrix_count += t.amatrix_count;
+            s->event_pair_ms += t.event_pair_ms; s->event_pair_count += t.event_pair_count;
         }
     }
     observables_t *o = system->observables;
