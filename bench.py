@@ -235,7 +235,14 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": sweep_avg_ms, "avg_launch_ms_with_event_pair": sweep_raw_ms,
                          "event_pair_ms": event_pair_ms, "launches": acc["sweep_count"],
-                         "algorithmic_bytes_per_launch": sweep_bytes},
+                         "algorithmic_bytes_per_launch": sweep_bytes,
+                         # SURVEY 8(d) asks for these two beside a sweep that does not stream a stored matrix:
+                         "pairs_per_s": (n_pol * (n_pol - 1) / 2) / (sweep_avg_ms * 1e-3) if sweep_avg_ms > 0 else 0.0,
+                         "effective_GBps_reference_layout": ((m3 * m3 * 8) / (sweep_avg_ms * 1e-3) / 1e9
+                                                             if sweep_avg_ms > 0 else 0.0),
+                         "note": "achieved = bytes this design moves (16 B per unordered pair); "
+                                 "effective_GBps_reference_layout prices the same time at the reference's (3N)^2 x 8 B "
+                                 "matrix and is not a bandwidth claim"},
             "device_ms_per_step": dict({k: brk[k] / nb for k in
                                         ("pair_ms", "recip_ms", "field_ms", "amatrix_ms", "sweep_ms", "palmo_ms",
                                          "other_ms", "total_ms")},

@@ -111,18 +111,25 @@ int mpmc_hip_device_count(void);
 int mpmc_hip_create(mpmc_hip_ctx **ctx, int device, int max_atoms);
 void mpmc_hip_destroy(mpmc_hip_ctx *ctx);
 
-/* Engine knobs that do not change results, for A/B measurement:
- *   "incremental_amatrix" (default 1): after mpmc_hip_update_atoms() rewrite only the moved atoms'
- *                          block-rows/-columns of the resident A matrix instead of rebuilding it;
+/* Engine knobs, for A/B measurement.  None changes what is computed; "pair_coefficients" and
+ * "symmetric_sweep" change the rounding of the sweep sums (1e-15 relative), the others are bit-neutral.
+ *   "pair_coefficients"   (default 1): Jacobi/SOR/ESOR/Palmo sweeps run on {c3, c5} per pair (16 B) with the
+ *                          geometry rebuilt in registers; 0 = on the expanded (3N)^2 A matrix (72 B per pair);
+ *   "incremental_amatrix" (default 1): after mpmc_hip_update_atoms() rewrite only the entries (coefficients,
+ *                          or block-rows/-columns of A) of pairs that involve a moved atom instead of rebuilding;
+ *   "incremental_pairs"   (default 1): the 64x64-atom tile partial sums of the LJ/Ewald pair kernel and of the
+ *                          static field persist between calls; only tiles of moved atoms' blocks are recomputed;
  *   "overlap_streams"     (default 1): run the LJ/Ewald kernels on a second HIP stream beside the
  *                          polarization chain;
- *   "symmetric_sweep"     (default 1): Jacobi/Palmo sweeps read only the upper triangle of A and use
- *                          every element for both products (half the HBM bytes); 0 = full-matrix sweep;
- *   "timing"              (default 1): 0 = record no HIP events; 1 = time the sweep kernels of every 4th
- *                          call; 2 = time every kernel class of every call (each event pair costs
- *                          ~4 microseconds of stream time: ~13 % of a 0.6 ms step);
+ *   "symmetric_sweep"     (default 1; with pair_coefficients = 0): sweeps read only the upper triangle of A and
+ *                          use every element for both products; 0 = full-matrix sweep; 2 = also below 2048 atoms;
+ *   "timing"              (default 1): 0 = record no HIP events; 1 = time the sweep kernels of every 8th
+ *                          call (plus an empty event pair for calibration); 2 = time every kernel class of every
+ *                          call (each event pair costs ~5 microseconds of stream time);
  *   "persistent_gs"       (default 1): Gauss-Seidel lower-triangle phase as one persistent kernel
- *                          (spine + owner workgroups); 0 = two launches per 64-atom block. */
+ *                          (spine + owner workgroups); 0 = two launches per 64-atom block;
+ *   "step_graph"          (default 0): replay a steady-state MC step as a HIP graph (bit-identical; measured
+ *                          slower than direct launches on ROCm 7.2). */
 int mpmc_hip_set_option(mpmc_hip_ctx *ctx, const char *name, int value);
 
 void mpmc_hip_default_params(mpmc_hip_params *p);
