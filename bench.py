@@ -90,6 +90,9 @@ def main():
     ap.add_argument("--corrtime", type=int, default=10)
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--uvt", action="store_true",
+                    help="grand-canonical chain (insert / remove / displace) with the flags of the reference's "
+                         "3_PCN61/iter.inp (insert_probability 0.666, pressure 70 atm as the fugacity) instead of NVT")
     ap.add_argument("--full-sweep", action="store_true", help="A/B: stream the full matrix instead of its upper triangle")
     ap.add_argument("--full-rebuild", action="store_true", help="A/B: rebuild A from scratch every step")
     ap.add_argument("--expanded-matrix", action="store_true",
@@ -115,7 +118,8 @@ def main():
     system, flags, label = load_workload(args.workload)
     n = len(system["charge"])
     # host control stays in C: system_t + energy() + the NVT chain of mpmc_amd/host/ drive the engine through the C ABI
-    chain = host.HostSystem(system, flags, device=local_rank, seed=args.seed + rank)
+    extra = {"ensemble": "uvt", "insert_probability": 0.666, "pressure": 70.0} if args.uvt else None
+    chain = host.HostSystem(system, flags, device=local_rank, seed=args.seed + rank, extra=extra)
     avg = WalkerAverages(dist=dist, device=dev)
     chain.energy()  # creates the device context, uploads the configuration
     if os.environ.get("MPMC_OVERLAP"):
@@ -228,7 +232,7 @@ def main():
             "data": "synthetic" if args.workload != "pcn61_4096" else
                     "reference sample geometry (PCN-61 cell carved from sample_configs_gpu/3_PCN61/input.pdb), "
                     "random MC moves",
-            "config": {"workload": label, "n_atoms": n, "n_polarizable": n_pol, "walkers": world, "corrtime": args.corrtime,
+            "config": {"workload": label + (" [UVT: insert/remove/displace]" if args.uvt else ""), "n_atoms": n, "n_polarizable": n_pol, "walkers": world, "corrtime": args.corrtime,
                        "parallelism": "%d independent walkers, 1 per GPU" % world},
             "roofline": {"kernel": kernel_name + " (Thole field / dipole sweep)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

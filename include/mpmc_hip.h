@@ -151,6 +151,20 @@ int mpmc_hip_upload(mpmc_hip_ctx *ctx, int n, const double *x, const double *y, 
 int mpmc_hip_update_atoms(mpmc_hip_ctx *ctx, int first, int count, const double *x, const double *y,
                           const double *z);
 
+/* Grand-canonical moves (mc_moves.c:583-697) without a re-upload: one molecule of `count` atoms enters or
+ * leaves the resident configuration.  The engine keeps its own atom order: an inserted molecule gets the
+ * slots [*first_slot, *first_slot + count) -- a hole left by a removed molecule of the same size, or new
+ * slots at the end -- and that slot range is what later update_atoms / remove_molecule calls and the
+ * per-atom downloads (which span mpmc_hip_slot_count() slots, holes reading as zeros) refer to.
+ * `mass` = atomic masses (the molecular mass is their sum), `frozen` applies to the whole molecule.
+ * Return 0 = done; 1 = cannot be done incrementally (context full, more than 16 atoms, Gauss-Seidel
+ * solver modes, incremental options off): upload the whole configuration again; < 0 = error. */
+int mpmc_hip_insert_molecule(mpmc_hip_ctx *ctx, int count, const double *x, const double *y, const double *z,
+                             const double *charge, const double *polarizability, const double *epsilon,
+                             const double *sigma, const double *mass, int frozen, int *first_slot);
+int mpmc_hip_remove_molecule(mpmc_hip_ctx *ctx, int first_slot, int count);
+int mpmc_hip_slot_count(mpmc_hip_ctx *ctx);
+
 /* One full energy() evaluation on the device. */
 int mpmc_hip_energy(mpmc_hip_ctx *ctx, mpmc_hip_result *out);
 

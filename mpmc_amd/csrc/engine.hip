@@ -107,6 +107,7 @@ struct SweepView {
     size_t Acap = 0;  // doubles
     bool A_valid = false;  // A matches the configuration as of the last energy() (minus `dirty` atoms)
     double2 *C = nullptr;  // pair-coefficient tiles {c3, c5} (kernels_coef.h), the default sweep storage
+    int ntld = 0;          // tile stride of C: the number of 64-atom tiles the view can grow to
     double *energy_part = nullptr;      // [cap/64][2] per-block sums for U_pol and <rrms>
     size_t Ccap = 0;       // double2 elements
     bool C_valid = false;
@@ -177,6 +178,13 @@ struct mpmc_hip_ctx {
     double *d_lrcpart = nullptr;    // scratch of the (cached) long-range correction
     DirtyBlocks dirty_blocks;       // of the energy() call in progress
     bool in_flight = false;         // between energy_begin() and energy_end()
+    // ---- grand-canonical edits (insert_molecule / remove_molecule): c->n is the number of atom SLOTS in use,
+    // some of which may be holes left by removed molecules
+    int n_valid = 0;                     // atoms actually present
+    int next_mol = 0;                    // next unused molecule id
+    std::vector<char> slot_valid;        // per atom slot
+    std::vector<std::pair<int, int>> holes;  // (first, count) of removed molecules, reusable by an insert of that size
+    std::vector<int> lrc_dirty_atoms;    // atoms inserted / removed since the long-range correction was summed
     // ---- one MC step as a HIP graph (see graph_step())
     int opt_graph = 0;                   // "step_graph": off by default, see graph_step()
     int graph_mode = 0;                  // GM_DIRECT | GM_CAPTURE | GM_UPDATE
@@ -612,9 +620,10 @@ extern "C" int mpmc_hip_upload(mpmc_hip_ctx *c, int n, const double *x, const do
         return fail("MPMC_HIP: upload: null array");
     HIPCHK(hipSetDevice(c->device));
     const int npad = round_up(n, 128);
-    std::vector<double> hx(npad, 0.0), hy(npad, 0.0), hz(npad, 0.0), hq(npad, 0.0), ha(npad, 0.0), he(npad, 0.0),
-        hs(npad, 0.0), hm(npad, 0.0);
-    std::vector<int> hmol(npad, -1), hfl(npad, 0);
+    const int nall = c->max_npad;  // every allocated slot is (re)initialised: later inserts may grow into them
+    std::vector<double> hx(nall, 0.0), hy(nall, 0.0), hz(nall, 0.0), hq(nall, 0.0), ha(nall, 0.0), he(nall, 0.0),
+        hs(nall, 0.0), hm(nall, 0.0);
+    std::vector<int> hmol(nall, -1), hfl(nall, 0);
     int m = -1;
     for (int i = 0; i < n; ++i) {
         if (i == 0 || molecule[i] != molecule[i - 1]) ++m;  // contiguous runs, read_pqr.c:278-287
@@ -636,8 +645,8 @@ extern "C" int mpmc_hip_upload(mpmc_hip_ctx *c, int n, const double *x, const do
         s = e;
     }
     // pad atoms: distinct molecule ids, far away; never valid
-    for (int i = n; i < npad; ++i) hmol[i] = -2 - i;
-    const size_t bd = npad * sizeof(double), bi = npad * sizeof(int);
+    for (int i = n; i < nall; ++i) hmol[i] = -2 - i;
+    const size_t bd = nall * sizeof(double), bi = nall * sizeof(int);
     HIPCHK(hipMemcpyAsync(c->d_x, hx.data(), bd, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->d_y, hy.data(), bd, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->d_z, hz.data(), bd, hipMemcpyHostToDevice, c->stream));
@@ -651,6 +660,11 @@ extern "C" int mpmc_hip_upload(mpmc_hip_ctx *c, int n, const double *x, const do
     HIPCHK(hipStreamSynchronize(c->stream));
     c->n = n;
     c->npad = npad;
+    c->n_valid = n;
+    c->next_mol = m + 1;
+    c->slot_valid.assign(n, 1);
+    c->holes.clear();
+    c->lrc_dirty_atoms.clear();
     c->have_atoms = true;
     c->have_polar_result = false;
     c->lrc_valid = false;
@@ -667,9 +681,12 @@ extern "C" int mpmc_hip_upload(mpmc_hip_ctx *c, int n, const double *x, const do
     v0.slot_of_atom.assign(n, -1);
     for (int k = 0; k < v0.nv; ++k) v0.slot_of_atom[v0.h_idx[k]] = k;
     {
-        std::vector<int> hs(npad, -1);
+        std::vector<int> hs(nall, -1);
         std::copy(v0.slot_of_atom.begin(), v0.slot_of_atom.end(), hs.begin());
-        HIPCHK(hipMemcpy(v0.d_slot, hs.data(), npad * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(v0.d_slot, hs.data(), nall * sizeof(int), hipMemcpyHostToDevice));
+    }
+    if (v0.C) {  // tiles beyond the ones the coming build rewrites must read as "no pair"
+        HIPCHK(hipMemsetAsync(v0.C, 0, v0.Ccap * sizeof(double2), c->stream));
     }
     c->all_dirty = true;
     c->dirty_atoms.clear();
@@ -761,6 +778,171 @@ extern "C" int mpmc_hip_update_atoms(mpmc_hip_ctx *c, int first, int count, cons
         else
             for (int i = 0; i < count; ++i) c->dirty_atoms.push_back(first + i);
     }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Grand-canonical moves without a re-upload.  The engine's atom order is its own business (sums are
+// over all atoms / pairs), so an inserted molecule takes the slots a removed one of the same size
+// left, or new slots at the end, and a removed molecule leaves holes; both then look like a "moved"
+// set of atoms to the incremental machinery (coefficient entries, pair / field / LRC tile partials).
+// Return value 1 = not possible incrementally (context full, molecule too large, a solver mode that
+// keeps ordered data): the caller uploads the whole configuration again.
+// ---------------------------------------------------------------------------------------------
+static bool edits_supported(const mpmc_hip_ctx *c) {
+    const mpmc_hip_params &P = c->par;
+    if (!c->have_atoms || c->all_dirty || !c->opt_incremental || !c->opt_incremental_pairs || !c->opt_pair_coef) return false;
+    if (!P.rd_only && P.polarization && (P.polar_gs || P.polar_gs_ranked)) return false;
+    return true;
+}
+
+static int launch_edits(mpmc_hip_ctx *c, const EditList &ed) {
+    SweepView &v0 = c->view[0];
+    EditTargets t;
+    t.x = c->d_x;
+    t.y = c->d_y;
+    t.z = c->d_z;
+    t.q = c->d_q;
+    t.alpha = c->d_alpha;
+    t.eps = c->d_eps;
+    t.sig = c->d_sig;
+    t.molmass = c->d_molmass;
+    t.mol = c->d_mol;
+    t.flags = c->d_flags;
+    t.slot_of_atom = v0.d_slot;
+    t.idx_of_slot = v0.d_idx;
+    t.px = v0.px;
+    t.py = v0.py;
+    t.pz = v0.pz;
+    t.palpha = v0.palpha;
+    t.pflags = v0.pflags;
+    if (flush_moves(c)) return -1;  // keep the order of the caller's operations
+    hipLaunchKernelGGL(apply_edits_kernel, dim3(1), dim3(64), 0, c->stream, ed, t);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static void mark_edited(mpmc_hip_ctx *c, int first, int count) {
+    for (int i = 0; i < count; ++i) {
+        c->dirty_atoms.push_back(first + i);
+        c->lrc_dirty_atoms.push_back(first + i);
+    }
+    if ((int)c->dirty_atoms.size() > 4 * kMaxDirty) c->all_dirty = true;
+    c->have_polar_result = false;
+    ++c->config_rev;
+}
+
+extern "C" int mpmc_hip_slot_count(mpmc_hip_ctx *c) { return c ? c->n : 0; }
+
+extern "C" int mpmc_hip_remove_molecule(mpmc_hip_ctx *c, int first, int count) {
+    if (!c || !c->have_atoms) return fail("MPMC_HIP: remove_molecule: no configuration uploaded");
+    if (c->in_flight) return fail("MPMC_HIP: remove_molecule between energy_begin() and energy_end()");
+    if (first < 0 || count <= 0 || first + count > c->n)
+        return fail("MPMC_HIP: remove_molecule: range [%d, %d) outside [0, %d)", first, first + count, c->n);
+    for (int i = 0; i < count; ++i)
+        if (!c->slot_valid[first + i]) return fail("MPMC_HIP: remove_molecule: slot %d holds no atom", first + i);
+    if (count > kMaxEdit || !edits_supported(c)) return 1;
+    HIPCHK(hipSetDevice(c->device));
+    SweepView &v0 = c->view[0];
+    EditList ed;
+    memset(&ed, 0, sizeof(ed));
+    ed.n = count;
+    for (int i = 0; i < count; ++i) {
+        ed.idx[i] = first + i;
+        ed.vslot[i] = v0.slot_of_atom[first + i];  // the view slot stays with the atom slot, as a hole
+        ed.mol[i] = -2 - (first + i);
+        ed.flags[i] = 0;
+        c->slot_valid[first + i] = 0;
+    }
+    if (launch_edits(c, ed)) return -1;
+    c->holes.push_back(std::make_pair(first, count));
+    c->n_valid -= count;
+    mark_edited(c, first, count);
+    return 0;
+}
+
+extern "C" int mpmc_hip_insert_molecule(mpmc_hip_ctx *c, int count, const double *x, const double *y, const double *z,
+                                        const double *charge, const double *polarizability, const double *epsilon,
+                                        const double *sigma, const double *mass, int frozen, int *first_slot) {
+    if (!c || !c->have_atoms) return fail("MPMC_HIP: insert_molecule: no configuration uploaded");
+    if (c->in_flight) return fail("MPMC_HIP: insert_molecule between energy_begin() and energy_end()");
+    if (count <= 0 || !x || !y || !z || !charge || !polarizability || !epsilon || !sigma || !mass || !first_slot)
+        return fail("MPMC_HIP: insert_molecule: bad arguments");
+    if (count > kMaxEdit || !edits_supported(c)) return 1;
+    HIPCHK(hipSetDevice(c->device));
+    SweepView &v0 = c->view[0];
+    // a hole of exactly this size (most recent first), else new slots at the end
+    int first = -1, hole = -1;
+    for (int h = (int)c->holes.size() - 1; h >= 0; --h)
+        if (c->holes[h].second == count) {
+            hole = h;
+            first = c->holes[h].first;
+            break;
+        }
+    if (first < 0) {
+        if (c->n + count > c->max_atoms) return 1;
+        first = c->n;
+    }
+    // view slots for the polarizable sites: the atom slot's old one if it has one, else appended
+    int new_view = 0;
+    for (int i = 0; i < count; ++i) {
+        const bool had = first + i < (int)v0.slot_of_atom.size() && v0.slot_of_atom[first + i] >= 0;
+        if (polarizability[i] != 0.0 && !had) ++new_view;
+    }
+    if (v0.nv + new_view > v0.cap) return 1;
+    if (hole >= 0)
+        c->holes.erase(c->holes.begin() + hole);
+    else {
+        c->n += count;
+        c->slot_valid.resize(c->n, 0);
+        v0.slot_of_atom.resize(c->n, -1);
+        c->perm.resize(c->n);
+        std::iota(c->perm.begin(), c->perm.end(), 0);
+        const int npad = round_up(c->n, 128);
+        if (npad != c->npad) {  // the tile grids of the pair / field / LRC partials change shape
+            c->npad = npad;
+            c->pair_part_valid = c->field_part_valid = false;
+            c->lrc_valid = false;
+        }
+    }
+    double mm = 0.0;
+    for (int i = 0; i < count; ++i) mm += mass[i];
+    const int mol = c->next_mol++;
+    EditList ed;
+    memset(&ed, 0, sizeof(ed));
+    ed.n = count;
+    for (int i = 0; i < count; ++i) {
+        const int a = first + i;
+        int s = v0.slot_of_atom[a];
+        if (polarizability[i] != 0.0 && s < 0) {
+            s = v0.nv++;
+            v0.slot_of_atom[a] = s;
+            v0.h_idx.resize(v0.nv);
+            v0.h_idx[s] = a;
+        }
+        ed.idx[i] = a;
+        ed.vslot[i] = s;
+        ed.mol[i] = mol;
+        ed.flags[i] = kValid | (frozen ? kFrozen : 0);
+        ed.x[i] = x[i];
+        ed.y[i] = y[i];
+        ed.z[i] = z[i];
+        ed.q[i] = charge[i];
+        ed.alpha[i] = polarizability[i];
+        ed.eps[i] = epsilon[i];
+        ed.sig[i] = sigma[i];
+        ed.molmass[i] = mm;
+        c->slot_valid[a] = 1;
+    }
+    const int nvpad = std::max(128, round_up(v0.nv, 128));
+    if (nvpad != v0.nvpad) {
+        v0.nvpad = nvpad;
+        v0.A_valid = false;
+    }
+    if (launch_edits(c, ed)) return -1;
+    c->n_valid += count;
+    mark_edited(c, first, count);
+    *first_slot = first;
     return 0;
 }
 
@@ -874,14 +1056,20 @@ static int ensure_coef_scratch(SweepView &v, int nt) {
     return 0;
 }
 
-static int ensure_view_coef(SweepView &v, int nt) {
-    const size_t need = (size_t)nt * nt * kCoefTile * kCoefTile;
-    if (v.Ccap < need) {
+static int ensure_view_coef(mpmc_hip_ctx *c, SweepView &v, int nt) {
+    // sized for every tile the view can grow to (insert_molecule appends to the view), so the tile stride
+    // never changes; tiles start out as zeros (= "no pair"), which is what unused slots must read as
+    const int ntld = std::max(nt, (v.cap + kCoefTile - 1) / kCoefTile);
+    const size_t need = (size_t)ntld * ntld * kCoefTile * kCoefTile;
+    if (v.Ccap < need || v.ntld != ntld) {
         if (v.C) hipFree(v.C);
         v.C = nullptr;
         v.Ccap = 0;
         HIPCHK(hipMalloc((void **)&v.C, need * sizeof(double2)));
+        // on the engine's stream: the non-blocking streams do not order themselves after the null stream
+        HIPCHK(hipMemsetAsync(v.C, 0, need * sizeof(double2), c->stream));
         v.Ccap = need;
+        v.ntld = ntld;
         v.C_valid = false;
     }
     return 0;
@@ -967,7 +1155,7 @@ static int launch_pair_kernel(mpmc_hip_ctx *c, const DevAtoms &a, const DevBox &
 static int launch_publish(mpmc_hip_ctx *c, bool do_polar) {
     HIPCHK(launch_slot(c, GS_PUBLISH, publish_result_kernel, dim3(1), dim3(64), c->stream, c->d_res, c->h_res_dev,
                        (int)R_COUNT, (double)c->energy_calls, do_polar ? c->energy_part : (const double *)nullptr,
-                       do_polar ? c->energy_nt : 0, c->n,
+                       do_polar ? c->energy_nt : 0, c->n_valid,
                        c->gs_used[0] ? (const unsigned *)(c->view[0].gsflags + 1) : (const unsigned *)nullptr,
                        c->gs_used[1] ? (const unsigned *)(c->view[1].gsflags + 1) : (const unsigned *)nullptr));
     return 0;
@@ -1031,13 +1219,33 @@ static int enqueue_direct(mpmc_hip_ctx *c) {
         side_rc = [&]() -> int {
         // ---- LJ long-range correction: parameters + volume only => cached (lj.c:56-107)
         if (P.rd_lrc) {
-            if (!c->lrc_valid) {
+            // depends on parameters, the volume and WHICH atoms exist -- not on coordinates: summed once, its
+            // tile partials kept, and only the tiles of inserted / removed atoms' blocks redone afterwards
+            DirtyBlocks lsel;
+            lsel.n = 0;
+            bool overflow = false;
+            for (int atom : c->lrc_dirty_atoms) {
+                const int b = atom / 64;
+                bool seen = false;
+                for (int k = 0; k < lsel.n; ++k) seen |= (lsel.blk[k] == b);
+                if (seen) continue;
+                if (lsel.n == kMaxDirtyBlocks) {
+                    overflow = true;
+                    break;
+                }
+                lsel.blk[lsel.n++] = b;
+            }
+            for (int k = lsel.n; k < kMaxDirtyBlocks; ++k) lsel.blk[k] = 0;
+            if (!c->lrc_valid || overflow) lsel.n = 0;
+            if (!c->lrc_valid || overflow || lsel.n > 0) {
                 ScopedTimer t(c, T_OTHER, sb);
-                hipLaunchKernelGGL(lj_lrc_kernel, dim3(ntile, ntile), dim3(64), 0, sb, a, bx, c->d_lrcpart);
+                hipLaunchKernelGGL(lj_lrc_kernel, dim3(ntile, lsel.n > 0 ? lsel.n : ntile), dim3(64), 0, sb, a, bx, lsel,
+                                   c->d_lrcpart);
                 hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(kReduceThreads), 0, sb, c->d_lrcpart, ntile * ntile, 1,
                                    c->d_res + R_LRC);
                 c->lrc_valid = true;
             }
+            c->lrc_dirty_atoms.clear();
         } else {
             HIPCHK(hipMemsetAsync(c->d_res + R_LRC, 0, sizeof(double), sb));
             c->lrc_valid = false;
@@ -1338,7 +1546,7 @@ extern "C" int mpmc_hip_energy_end(mpmc_hip_ctx *c, mpmc_hip_result *out) {
     out->polar_ewald_alpha = c->polar_ewald_alpha;
     out->polar_iterations = polar_iterations;
     out->iter_success = iter_success;
-    out->n_atoms = c->n;
+    out->n_atoms = c->n_valid;
     out->status = std::isfinite(out->energy) ? 0 : 1;
     return 0;
 }

@@ -13,7 +13,7 @@
 //
 // Storage: 64 x 64-pair tiles (ti <= tj), "rotated" so that the access of the sweep is coalesced:
 //     element (l, s) of tile (ti, tj) is the pair  i = 64 ti + l,  j = 64 tj + ((l + s) & 63)
-//     C[((ti * nt + tj) * 64 + s) * 64 + l] = {c3, c5}            (nt = ceil(nv / 64))
+//     C[((ti * ntld + tj) * 64 + s) * 64 + l] = {c3, c5}          (ntld = tiles the view can grow to)
 // At step s lane l of a wave works on row atom l and column atom (l + s) & 63: the row sums stay in
 // the lane, the column sums travel one lane per step (DPP wave_rol:1), the column atoms' coordinates
 // and dipoles are read from LDS at a rotating, conflict-free index.  A diagonal tile holds every
@@ -88,7 +88,7 @@ __device__ __forceinline__ double2 stream_load_coef(const double2 *p) {
 // grid = (nt [tj], nt [ti]); block = 256 (wave w fills steps 16 w .. 16 w + 15); tiles below the
 // diagonal exit.  `a` is the view's atom set (coordinates / flags in slot order).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64 * kCoefWaves) void build_coef_kernel(DevAtoms a, DevBox bx, double damp, int nt,
+__global__ __launch_bounds__(64 * kCoefWaves) void build_coef_kernel(DevAtoms a, DevBox bx, double damp, int ntld,
                                                                        double2 *__restrict__ C) {
     const int tj = blockIdx.x, ti = blockIdx.y;
     if (tj < ti) return;
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(64 * kCoefWaves) void build_coef_kernel(DevAtoms a,
     const double xi = a.x[64 * ti + l], yi = a.y[64 * ti + l], zi = a.z[64 * ti + l];
     const bool vi = a.flags[64 * ti + l] & kValid;
     __syncthreads();
-    double2 *tile = C + (size_t)(ti * nt + tj) * (kCoefTile * kCoefTile);
+    double2 *tile = C + (size_t)(ti * ntld + tj) * (kCoefTile * kCoefTile);
     for (int s = kCoefSteps * w; s < kCoefSteps * (w + 1); ++s) {
         const int jj = (l + s) & 63;
         double c3 = 0.0, c5 = 0.0, dx, dy, dz;
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(64 * kCoefWaves) void build_coef_kernel(DevAtoms a,
 // grid = (nt, ndirty); block = 64: thread = partner k of dirty slot a.  A pair of two moved atoms is
 // written by both (same value).  Same function of the same coordinates as the full build, hence
 // bit-identical to it.
-__global__ __launch_bounds__(64) void update_coef_kernel(DevAtoms a, DevBox bx, double damp, DirtyList dirty, int nt,
+__global__ __launch_bounds__(64) void update_coef_kernel(DevAtoms a, DevBox bx, double damp, DirtyList dirty, int ntld,
                                                           double2 *__restrict__ C) {
     const int sa = dirty.slot[blockIdx.y];
     const int k = blockIdx.x * 64 + threadIdx.x;
@@ -134,11 +134,11 @@ __global__ __launch_bounds__(64) void update_coef_kernel(DevAtoms a, DevBox bx, 
     const double2 v = make_double2(c3, c5);
     const size_t tsz = kCoefTile * kCoefTile;
     if (ta < tk) {
-        C[(size_t)(ta * nt + tk) * tsz + ((lk - la) & 63) * 64 + la] = v;
+        C[(size_t)(ta * ntld + tk) * tsz + ((lk - la) & 63) * 64 + la] = v;
     } else if (ta > tk) {
-        C[(size_t)(tk * nt + ta) * tsz + ((la - lk) & 63) * 64 + lk] = v;
+        C[(size_t)(tk * ntld + ta) * tsz + ((la - lk) & 63) * 64 + lk] = v;
     } else {
-        double2 *tile = C + (size_t)(ta * nt + ta) * tsz;
+        double2 *tile = C + (size_t)(ta * ntld + ta) * tsz;
         tile[((lk - la) & 63) * 64 + la] = v;
         tile[((la - lk) & 63) * 64 + lk] = v;
     }
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(64 * kCoefFinishGroups) void pair_finish_kernel(int
 }
 
 template <int ORTHO>
-__global__ __launch_bounds__(64 * kCoefWaves) void pair_sweep_kernel(const double2 *__restrict__ C, int nt,
+__global__ __launch_bounds__(64 * kCoefWaves) void pair_sweep_kernel(const double2 *__restrict__ C, int nt, int ntld,
                                                                        const double *__restrict__ x,
                                                                        const double *__restrict__ y,
                                                                        const double *__restrict__ z,
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(64 * kCoefWaves) void pair_sweep_kernel(const doubl
     const int i = 64 * ti + l;
     const double xi = x[i], yi = y[i], zi = z[i];
     const double mix = mu[3 * i], miy = mu[3 * i + 1], miz = mu[3 * i + 2];
-    const double2 *tile = C + (size_t)(ti * nt + tj) * (kCoefTile * kCoefTile) + (size_t)(kCoefSteps * w) * 64 + l;
+    const double2 *tile = C + (size_t)(ti * ntld + tj) * (kCoefTile * kCoefTile) + (size_t)(kCoefSteps * w) * 64 + l;
     double2 c[kCoefSteps];
 #pragma unroll
     for (int k = 0; k < kCoefSteps; ++k) c[k] = stream_load_coef(tile + 64 * k);

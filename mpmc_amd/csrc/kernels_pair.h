@@ -210,9 +210,19 @@ __global__ __launch_bounds__(64 * kPairWaves) void pair_rd_es_kernel(DevAtoms a,
 // (same-molecule pairs INCLUDED, lj.c:56-83) + per-atom self part (lj.c:85-107).  Depends only
 // on parameters and the volume, so it is evaluated at upload / box change, like the
 // reference's cached pair_ptr->lrc.
-__global__ __launch_bounds__(64) void lj_lrc_kernel(DevAtoms a, DevBox bx, double *__restrict__ partials) {
-    const int I = blockIdx.y, J = blockIdx.x;
+// Tile partials persist like the pair kernel's; an incremental pass (sel.n > 0, grid = (npad/64, sel.n))
+// redoes the tiles of the blocks whose atoms were inserted or removed.
+__global__ __launch_bounds__(64) void lj_lrc_kernel(DevAtoms a, DevBox bx, DirtyBlocks sel,
+                                                     double *__restrict__ partials) {
+    int I = blockIdx.y, J = blockIdx.x;
     const int lane = threadIdx.x;
+    if (sel.n > 0) {
+        const int d = sel.blk[blockIdx.y], o = blockIdx.x;
+        for (int k = 0; k < (int)blockIdx.y; ++k)
+            if (sel.blk[k] == o) return;
+        I = min(d, o);
+        J = max(d, o);
+    }
     double *out = partials + (size_t)(I * gridDim.x + J);
     if (J < I) {
         if (lane == 0) out[0] = 0.0;

@@ -400,6 +400,56 @@ __global__ __launch_bounds__(64) void apply_moves_kernel(MoveList m, double *__r
     }
 }
 
+// Insertion / removal of one molecule (grand-canonical moves), by value in the kernel arguments like a
+// MoveList: every per-atom array of the configuration and of sweep view 0 is patched in place.  A removed
+// atom keeps its coordinates and becomes a hole (flags = 0, q = alpha = eps = sigma = 0).
+constexpr int kMaxEdit = 16;
+struct EditList {
+    int n;
+    int idx[kMaxEdit];    // atom slot
+    int vslot[kMaxEdit];  // slot in sweep view 0, or -1
+    int mol[kMaxEdit], flags[kMaxEdit];
+    double x[kMaxEdit], y[kMaxEdit], z[kMaxEdit], q[kMaxEdit], alpha[kMaxEdit], eps[kMaxEdit], sig[kMaxEdit],
+        molmass[kMaxEdit];
+};
+struct EditTargets {
+    double *x, *y, *z, *q, *alpha, *eps, *sig, *molmass;
+    int *mol, *flags;
+    int *slot_of_atom, *idx_of_slot;
+    double *px, *py, *pz, *palpha;
+    int *pflags;
+};
+
+__global__ __launch_bounds__(64) void apply_edits_kernel(EditList e, EditTargets t) {
+    const int k = threadIdx.x;
+    if (k >= e.n) return;
+    const int a = e.idx[k], s = e.vslot[k];
+    const bool valid = e.flags[k] & kValid;
+    if (valid) {
+        t.x[a] = e.x[k];
+        t.y[a] = e.y[k];
+        t.z[a] = e.z[k];
+    }
+    t.q[a] = e.q[k];
+    t.alpha[a] = e.alpha[k];
+    t.eps[a] = e.eps[k];
+    t.sig[a] = e.sig[k];
+    t.molmass[a] = e.molmass[k];
+    t.mol[a] = e.mol[k];
+    t.flags[a] = e.flags[k];
+    t.slot_of_atom[a] = s;
+    if (s >= 0) {
+        t.idx_of_slot[s] = a;
+        if (valid) {
+            t.px[s] = e.x[k];
+            t.py[s] = e.y[k];
+            t.pz[s] = e.z[k];
+        }
+        t.palpha[s] = e.alpha[k];
+        t.pflags[s] = e.flags[k];
+    }
+}
+
 struct DirtyList {  // passed by value in the kernel arguments: no H2D copy on the step's critical path
     int slot[64];
 };

@@ -141,7 +141,8 @@ class HostSystem:
         return dict(pos=pos, molecule=mol, frozen=frz, basis=np.asarray(basis, dtype=np.float64), **f)
 
     def dipoles(self):
-        mu, es, ei = (np.zeros((self.n, 3)) for _ in range(3))
+        n = self.natoms()  # differs from the initial count under uvt
+        mu, es, ei = (np.zeros((n, 3)) for _ in range(3))
         if self.lib.host_get_dipoles(self.ptr, mu.ctypes.data, es.ctypes.data, ei.ctypes.data):
             raise engine.EngineError(engine.load().mpmc_hip_last_error().decode())
         return dict(mu=mu, ef_static=es, ef_induced=ei)

@@ -30,6 +30,7 @@ int host_apply_config(system_t *system, const char *text) {
 }
 
 /* run `nsteps` more MC steps on an initialised chain; returns accepted count */
+void host_profile_report(void);
 int host_mc_steps(system_t *system, int nsteps) {
     int acc0 = system->nodestats->accept;
     if (system->step == 0 && system->avg_observables->counter == 0.0) {

@@ -9,18 +9,47 @@
  * are sent (one molecule after make_move(), the same one again after restore()).
  */
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "mpmc_host.h"
 
+/* Host image of what the device holds, indexed by DEVICE SLOT (the engine keeps its own atom order once
+ * molecules are inserted / removed, see mpmc_hip_insert_molecule): coordinates as last sent, and for the first
+ * slot of every resident molecule its ticket, atom count and the energy() call that last saw it. */
 typedef struct {
-    int n, cap;
-    double *x, *y, *z;      /* shadow of what the device holds */
-    double *tx, *ty, *tz;   /* scratch */
+    int cap;                     /* slots allocated */
+    double *x, *y, *z;
+    unsigned long long *ticket;  /* [first slot] 0 = no molecule starts here */
+    int *count;                  /* [first slot] atoms of that molecule */
+    unsigned long long *seen;    /* [first slot] epoch of the last walk that found it */
+    int *first;                  /* first slots of the resident molecules (unordered) */
+    int nfirst;
+    unsigned long long epoch, next_ticket;
 } shadow_t;
 
-static shadow_t g_shadow; /* one engine per process, like the reference's one system per process */
+/* one image per system_t (a process may hold several systems, each with its own engine context) */
+static shadow_t *shadow_of(system_t *system) {
+    if (!system->hip_shadow) system->hip_shadow = calloc(1, sizeof(shadow_t));
+    return (shadow_t *)system->hip_shadow;
+}
+void hip_free_shadow(system_t *system) {
+    shadow_t *sh = (shadow_t *)system->hip_shadow;
+    if (!sh) return;
+    free(sh->x); free(sh->y); free(sh->z); free(sh->ticket); free(sh->count); free(sh->seen); free(sh->first);
+    free(sh);
+    system->hip_shadow = NULL;
+}
+static double g_prof[4]; /* MPMC_HIP_HOST_PROFILE: seconds in walk+diff, begin, bookkeeping, end */
+static long g_prof_calls;
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+void host_profile_report(void) {
+    if (getenv("MPMC_HIP_HOST_PROFILE") && g_prof_calls)
+        fprintf(stderr, "host energy(): %ld calls; walk+diff %.1f us, begin %.1f us, bookkeeping %.1f us, end %.1f us per call\n", g_prof_calls,
+                1e6 * g_prof[0] / g_prof_calls, 1e6 * g_prof[1] / g_prof_calls, 1e6 * g_prof[2] / g_prof_calls, 1e6 * g_prof[3] / g_prof_calls);
+} /* one engine per process, like the reference's one system per process */
 
 /* reference countNatoms(), energy.c:36-46 */
 int countNatoms(system_t *system) {
@@ -88,27 +117,48 @@ static int hip_fail(const char *what) {
     return -1;
 }
 
+static int shadow_reserve(shadow_t *sh, int cap) {
+    if (sh->cap >= cap) return 0;
+    free(sh->x); free(sh->y); free(sh->z); free(sh->ticket); free(sh->count); free(sh->seen); free(sh->first);
+    sh->x = malloc(cap * sizeof(double)); sh->y = malloc(cap * sizeof(double)); sh->z = malloc(cap * sizeof(double));
+    sh->ticket = calloc(cap, sizeof(unsigned long long));
+    sh->count = calloc(cap, sizeof(int));
+    sh->seen = calloc(cap, sizeof(unsigned long long));
+    sh->first = malloc(cap * sizeof(int));
+    sh->cap = cap;
+    return (sh->x && sh->y && sh->z && sh->ticket && sh->count && sh->seen && sh->first) ? 0 : -1;
+}
+
+/* whole configuration, slots = list order */
 static int full_upload(system_t *system) {
     const int n = system->natoms;
-    shadow_t *sh = &g_shadow;
-    if (sh->cap < n) {
-        free(sh->x); free(sh->y); free(sh->z); free(sh->tx); free(sh->ty); free(sh->tz);
-        sh->x = malloc(n * sizeof(double)); sh->y = malloc(n * sizeof(double)); sh->z = malloc(n * sizeof(double));
-        sh->tx = malloc(n * sizeof(double)); sh->ty = malloc(n * sizeof(double)); sh->tz = malloc(n * sizeof(double));
-        sh->cap = n;
-    }
+    shadow_t *sh = shadow_of(system);
+    if (shadow_reserve(sh, system->hip_capacity > n ? system->hip_capacity : n)) return -1;
+    memset(sh->ticket, 0, sh->cap * sizeof(unsigned long long));
+    sh->nfirst = 0;
     double *q = malloc(n * sizeof(double)), *al = malloc(n * sizeof(double)), *ep = malloc(n * sizeof(double)),
            *sg = malloc(n * sizeof(double)), *ms = malloc(n * sizeof(double));
     int *mol = malloc(n * sizeof(int));
     uint8_t *fz = malloc(n);
     int i = 0, mi = 0;
-    for (molecule_t *m = system->molecules; m; m = m->next, mi++)
+    ++sh->epoch;
+    for (molecule_t *m = system->molecules; m; m = m->next, mi++) {
+        const int first = i;
         for (atom_t *a = m->atoms; a; a = a->next, i++) {
             sh->x[i] = a->pos[0]; sh->y[i] = a->pos[1]; sh->z[i] = a->pos[2];
             q[i] = a->charge; al[i] = a->polarizability; ep[i] = a->epsilon; sg[i] = a->sigma; ms[i] = a->mass;
             mol[i] = mi; /* list position: distinct per molecule even if PQR ids repeat */
             fz[i] = (uint8_t)(a->frozen != 0);
         }
+        if (i > first) {
+            m->hip_slot = first;
+            m->hip_ticket = ++sh->next_ticket;
+            sh->ticket[first] = m->hip_ticket;
+            sh->count[first] = i - first;
+            sh->seen[first] = sh->epoch;
+            sh->first[sh->nfirst++] = first;
+        }
+    }
     double basis[9];
     for (int p = 0; p < 3; p++)
         for (int r = 0; r < 3; r++) basis[3 * p + r] = system->pbc->basis[p][r];
@@ -119,56 +169,86 @@ static int full_upload(system_t *system) {
     if (!rc) rc = mpmc_hip_upload(system->hip_ctx, n, sh->x, sh->y, sh->z, q, al, ep, sg, ms, mol, fz);
     free(q); free(al); free(ep); free(sg); free(ms); free(mol); free(fz);
     if (rc) return hip_fail("upload");
-    sh->n = n;
     system->hip_uploaded_natoms = n;
     system->hip_dirty_all = 0;
     return 0;
 }
 
-/* send only what changed since the previous call: one short range per moved molecule (after a rejected
- * move two molecules differ from the device copy -- the restored one and the newly displaced one -- and
- * they can be far apart in the list, so changed atoms are grouped into separate ranges) */
-/* One walk over the molecule lists: counts the atoms (reference countNatoms(), energy.c:36-46) and, while
- * they still fit the shadow arrays, collects their coordinates for the comparison in delta_upload(). */
-static int collect_positions(system_t *system) {
-    shadow_t *sh = &g_shadow;
-    int i = 0;
-    for (molecule_t *m = system->molecules; m; m = m->next)
-        for (atom_t *a = m->atoms; a; a = a->next, i++)
-            if (i < sh->cap) {
-                sh->tx[i] = a->pos[0]; sh->ty[i] = a->pos[1]; sh->tz[i] = a->pos[2];
-            }
-    return i;
-}
-
-static int delta_upload(system_t *system) {
-    shadow_t *sh = &g_shadow;
-    const int n = system->natoms;
-    int i;
-    int lo = -1, hi = -1; /* current open range */
-    for (i = 0; i <= n; i++) {
-        const int changed = (i < n) && (sh->tx[i] != sh->x[i] || sh->ty[i] != sh->y[i] || sh->tz[i] != sh->z[i]);
-        if (changed) {
-            if (lo < 0) lo = i;
-            hi = i;
+/* Bring the device in line with the molecule lists without a re-upload.  One walk: a molecule whose ticket
+ * still owns its slots is resident -- its atoms are compared with what was last sent and re-sent if they moved
+ * (one molecule after make_move(), two after a rejected move: the restored one and the new trial) --, any other
+ * molecule is new (a grand-canonical insertion, or the backup of a rejected removal) and is inserted; resident
+ * molecules the walk did not meet were removed.  Returns 1 when the engine wants the whole configuration
+ * again (context full, solver mode without incremental edits), < 0 on error. */
+static int sync_device(system_t *system) {
+    shadow_t *sh = shadow_of(system);
+    mpmc_hip_ctx *ctx = system->hip_ctx;
+    ++sh->epoch;
+    molecule_t *fresh[8];
+    int nfresh = 0;
+    double tx[64], ty[64], tz[64];
+    for (molecule_t *m = system->molecules; m; m = m->next) {
+        const int s = m->hip_slot;
+        /* (a second molecule presenting a ticket already met in this walk is a copy that kept its parent's) */
+        if (m->hip_ticket == 0 || s < 0 || s >= sh->cap || sh->ticket[s] != m->hip_ticket || sh->seen[s] == sh->epoch) {
+            if (nfresh == 8) return 1;
+            fresh[nfresh++] = m;
+            continue;
         }
-        /* close the range once 8 unchanged atoms (or the end) follow it */
-        if (lo >= 0 && (i == n || (!changed && i - hi >= 8))) {
-            const int cnt = hi - lo + 1;
-            if (mpmc_hip_update_atoms(system->hip_ctx, lo, cnt, sh->tx + lo, sh->ty + lo, sh->tz + lo))
-                return hip_fail("update_atoms");
-            memcpy(sh->x + lo, sh->tx + lo, cnt * sizeof(double));
-            memcpy(sh->y + lo, sh->ty + lo, cnt * sizeof(double));
-            memcpy(sh->z + lo, sh->tz + lo, cnt * sizeof(double));
-            lo = hi = -1;
+        sh->seen[s] = sh->epoch;
+        int k = 0, moved = 0;
+        for (atom_t *a = m->atoms; a; a = a->next, k++)
+            moved |= (a->pos[0] != sh->x[s + k]) | (a->pos[1] != sh->y[s + k]) | (a->pos[2] != sh->z[s + k]);
+        if (!moved) continue;
+        k = 0;
+        for (atom_t *a = m->atoms; a; a = a->next, k++) {
+            sh->x[s + k] = a->pos[0]; sh->y[s + k] = a->pos[1]; sh->z[s + k] = a->pos[2];
         }
+        if (mpmc_hip_update_atoms(ctx, s, k, sh->x + s, sh->y + s, sh->z + s)) return hip_fail("update_atoms");
     }
+    /* removals first, so that an insertion of the same size can take the slots */
+    for (int f = 0; f < sh->nfirst;) {
+        const int s = sh->first[f];
+        if (sh->seen[s] == sh->epoch) {
+            f++;
+            continue;
+        }
+        const int rc = mpmc_hip_remove_molecule(ctx, s, sh->count[s]);
+        if (rc < 0) return hip_fail("remove_molecule");
+        if (rc > 0) return 1;
+        sh->ticket[s] = 0;
+        sh->first[f] = sh->first[--sh->nfirst];
+    }
+    for (int f = 0; f < nfresh; f++) {
+        molecule_t *m = fresh[f];
+        double q[64], al[64], ep[64], sg[64], ms[64];
+        int k = 0;
+        for (atom_t *a = m->atoms; a; a = a->next, k++) {
+            if (k == 64) return 1;
+            tx[k] = a->pos[0]; ty[k] = a->pos[1]; tz[k] = a->pos[2];
+            q[k] = a->charge; al[k] = a->polarizability; ep[k] = a->epsilon; sg[k] = a->sigma; ms[k] = a->mass;
+        }
+        int s = -1;
+        const int rc = mpmc_hip_insert_molecule(ctx, k, tx, ty, tz, q, al, ep, sg, ms, m->frozen != 0, &s);
+        if (rc < 0) return hip_fail("insert_molecule");
+        if (rc > 0 || s < 0 || s + k > sh->cap) return 1;
+        for (int i = 0; i < k; i++) {
+            sh->x[s + i] = tx[i]; sh->y[s + i] = ty[i]; sh->z[s + i] = tz[i];
+        }
+        m->hip_slot = s;
+        m->hip_ticket = ++sh->next_ticket;
+        sh->ticket[s] = m->hip_ticket;
+        sh->count[s] = k;
+        sh->seen[s] = sh->epoch;
+        sh->first[sh->nfirst++] = s;
+    }
+    system->hip_uploaded_natoms = system->natoms;
     return 0;
 }
 
-/* returns the total potential energy for the system and updates our observables */
 double energy(system_t *system) {
-    system->natoms = collect_positions(system);
+    const double t0 = now_s();
+    system->natoms = countNatoms(system);
     if (system->hip_ctx && system->natoms > system->hip_capacity) { /* uvt grew past the context */
         mpmc_hip_destroy(system->hip_ctx);
         system->hip_ctx = NULL;
@@ -182,25 +262,35 @@ double energy(system_t *system) {
         }
         system->hip_dirty_all = 1;
     }
-    if (system->hip_dirty_all || system->hip_uploaded_natoms != system->natoms ||
-        system->last_volume != system->pbc->volume) {
+    int need_upload = system->hip_dirty_all || system->last_volume != system->pbc->volume;
+    if (!need_upload) {
+        const int rc = sync_device(system);
+        if (rc < 0) return NAN;
+        need_upload = rc;
+    }
+    if (need_upload) {
         if (system->last_volume != system->pbc->volume) pbc(system);
         if (full_upload(system)) return NAN;
-    } else if (delta_upload(system))
-        return NAN;
+    }
 
     /* the device works while the host does the bookkeeping that does not need the energies */
     mpmc_hip_result r;
+    const double t1 = now_s();
     if (mpmc_hip_energy_begin(system->hip_ctx)) {
         hip_fail("energy");
         return NAN;
     }
+    const double t2 = now_s();
     update_com(system->molecules); /* pairs.c:331 */
     countN(system);
+    const double t3 = now_s();
     if (mpmc_hip_energy_end(system->hip_ctx, &r)) {
         hip_fail("energy");
         return NAN;
     }
+    const double t4 = now_s();
+    g_prof[0] += t1 - t0; g_prof[1] += t2 - t1; g_prof[2] += t3 - t2; g_prof[3] += t4 - t3;
+    g_prof_calls++;
     if (system->hip_timing) {
         mpmc_hip_timings t;
         if (!mpmc_hip_get_timings(system->hip_ctx, &t)) {
@@ -229,15 +319,15 @@ double energy(system_t *system) {
 /* atom->mu / ef_static / ef_induced as polar() leaves them; called where the reference reads them
  * (write_dipole / write_field at corrtime, src/mc/mc.c:398-414) instead of on every step */
 int hip_download_dipoles(system_t *system) {
-    const int n = system->natoms;
+    const int n = mpmc_hip_slot_count(system->hip_ctx); /* device slots, holes included */
     double *buf = malloc(4 * 3 * (size_t)n * sizeof(double));
     double *mu = buf, *es = buf + 3 * n, *ei = buf + 6 * n, *ec = buf + 9 * n;
     if (mpmc_hip_download_dipoles(system->hip_ctx, mu, es, ei, ec)) {
         free(buf);
         return hip_fail("download_dipoles");
     }
-    int i = 0;
-    for (molecule_t *m = system->molecules; m; m = m->next)
+    for (molecule_t *m = system->molecules; m; m = m->next) {
+        int i = m->hip_slot;
         for (atom_t *a = m->atoms; a; a = a->next, i++)
             for (int p = 0; p < 3; p++) {
                 a->mu[p] = mu[3 * i + p];
@@ -245,6 +335,7 @@ int hip_download_dipoles(system_t *system) {
                 a->ef_induced[p] = ei[3 * i + p];
                 a->ef_induced_change[p] = ec[3 * i + p];
             }
+    }
     free(buf);
     return 0;
 }

@@ -446,9 +446,13 @@ system_t *system_from_arrays(int n, const double *pos, const double *charge, con
     return system;
 }
 
+void host_profile_report(void);
+void hip_free_shadow(system_t *system);
 void free_system(system_t *system) {
     if (!system) return;
+    host_profile_report();
     if (system->hip_ctx) mpmc_hip_destroy(system->hip_ctx);
+    hip_free_shadow(system);
     molecule_t *m = system->molecules;
     while (m) {
         atom_t *a = m->atoms;

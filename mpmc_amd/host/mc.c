@@ -215,6 +215,8 @@ void make_move(system_t *system) {
                 for (int q = 0; q < 3; q++) com[p] += system->pbc->basis[q][p] * rand[q];
             }
             molecule_t *ins = cp->molecule_backup;
+            ins->hip_ticket = 0; /* a new molecule: it does not own the slots of the one it was copied from */
+            ins->hip_slot = -1;
             for (atom_t *a = ins->atoms; a; a = a->next)
                 for (int p = 0; p < 3; p++) a->pos[p] += com[p] - ins->com[p];
             for (int p = 0; p < 3; p++) ins->com[p] = com[p];

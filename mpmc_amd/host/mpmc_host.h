@@ -51,6 +51,11 @@ typedef struct _molecule {
     double com[3], wrapped_com[3];
     atom_t *atoms;
     struct _molecule *next;
+    /* HIP engine residency: first device slot of the molecule's atoms and the ticket that proves the slots are
+     * still this molecule's (copied by copy_molecule(), so a restored backup keeps its place; cleared on the copy
+     * that make_move() inserts) */
+    int hip_slot;
+    unsigned long long hip_ticket;
 } molecule_t;
 
 typedef struct _pbc {
@@ -114,6 +119,7 @@ typedef struct _system {
     double last_volume;
     /* device engine (opaque to callers) */
     mpmc_hip_ctx *hip_ctx;
+    void *hip_shadow; /* host image of the device configuration (energy_hip.c) */
     int hip_device, hip_uploaded_natoms, hip_dirty_all, hip_capacity;
     mpmc_hip_timings hip_timings_sum; /* accumulated over energy() calls since mc() started */
     int hip_timing;

@@ -80,6 +80,44 @@ def test_uvt_chain_inserts_removes_and_tracks_the_oracle():
     h.close()
 
 
+def test_uvt_incremental_edits_match_full_reuploads():
+    """Insertions and removals reach the device as edits of the resident configuration
+    (mpmc_hip_insert_molecule / remove_molecule: holes, reused slots, appended view slots).  The same chain
+    with those edits disabled -- every N change a full upload -- must walk the same path: identical accept /
+    reject decisions and atom counts, energies equal to rounding (the two keep different atom orders), and the
+    per-atom dipoles mapped back through the slots must match the oracle."""
+    s = synth.s_pol(160, spacing=4.5)
+    p = dict(temperature=77.0, polarization=1, polar_damp=2.1304, polar_max_iter=4, feynman_hibbs=1,
+             feynman_hibbs_order=4)
+    # one chain after the other: the host layer has ONE Mersenne twister per process, like the reference
+    chains, trace = [], [[], []]
+    for k, incremental in enumerate((1, 0)):
+        h = host.HostSystem(s, p, seed=33, move_factor=0.05, rot_factor=0.05,
+                            extra={"ensemble": "uvt", "insert_probability": 0.7, "pressure": 300.0})
+        h.energy()  # creates the context
+        h.set_option("incremental_amatrix", incremental)  # 0: the engine asks for re-uploads instead of edits
+        for _ in range(15):
+            acc = h.mc_steps(8)
+            trace[k].append((acc, h.natoms(), h.observables()["energy"]))
+        chains.append(h)
+    ns = {t[1] for t in trace[0]}
+    assert len(ns) > 2, "N hardly changed"
+    for a, b in zip(*trace):
+        assert a[0] == b[0] and a[1] == b[1]
+        assert abs(a[2] - b[2]) <= 1e-10 * max(1.0, abs(b[2]))
+    for h in chains:
+        final = h.system(s["basis"])
+        want = oracle.energy(final, p, want_vectors=True)
+        o = h.observables()
+        assert abs(o["energy"] - want["energy"]) < 1e-9 * max(1.0, abs(want["energy"]))
+        e = h.energy()  # the device may still hold a rejected trial: evaluate the configuration the chain kept
+        assert abs(e - want["energy"]) < 1e-9 * max(1.0, abs(want["energy"]))
+        d = h.dipoles()
+        assert np.abs(d["mu"] - want["mu"]).max() <= 1e-9 * np.abs(want["mu"]).max()
+        assert np.abs(d["ef_static"] - want["ef_static"]).max() <= 1e-9 * np.abs(want["ef_static"]).max()
+        h.close()
+
+
 def test_driver_executable_on_reference_style_input():
     """mpmc_hip <input> on the 10-atom box: the step-0 line of its energy_output must carry the
     reference's golden numbers (sample_configs_gpu/cuda_pol.small/noncuda_control/small.energy.dat:2)."""
