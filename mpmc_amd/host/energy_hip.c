@@ -185,7 +185,7 @@ static int sync_device(system_t *system) {
     mpmc_hip_ctx *ctx = system->hip_ctx;
     ++sh->epoch;
     molecule_t *fresh[8];
-    int nfresh = 0;
+    int nfresh = 0, natoms = 0;
     double tx[64], ty[64], tz[64];
     for (molecule_t *m = system->molecules; m; m = m->next) {
         const int s = m->hip_slot;
@@ -193,12 +193,14 @@ static int sync_device(system_t *system) {
         if (m->hip_ticket == 0 || s < 0 || s >= sh->cap || sh->ticket[s] != m->hip_ticket || sh->seen[s] == sh->epoch) {
             if (nfresh == 8) return 1;
             fresh[nfresh++] = m;
+            for (atom_t *a = m->atoms; a; a = a->next) natoms++;
             continue;
         }
         sh->seen[s] = sh->epoch;
         int k = 0, moved = 0;
         for (atom_t *a = m->atoms; a; a = a->next, k++)
             moved |= (a->pos[0] != sh->x[s + k]) | (a->pos[1] != sh->y[s + k]) | (a->pos[2] != sh->z[s + k]);
+        natoms += k;
         if (!moved) continue;
         k = 0;
         for (atom_t *a = m->atoms; a; a = a->next, k++) {
@@ -242,33 +244,33 @@ static int sync_device(system_t *system) {
         sh->seen[s] = sh->epoch;
         sh->first[sh->nfirst++] = s;
     }
-    system->hip_uploaded_natoms = system->natoms;
+    system->natoms = natoms;
+    system->hip_uploaded_natoms = natoms;
     return 0;
 }
 
 double energy(system_t *system) {
     const double t0 = now_s();
-    system->natoms = countNatoms(system);
-    if (system->hip_ctx && system->natoms > system->hip_capacity) { /* uvt grew past the context */
-        mpmc_hip_destroy(system->hip_ctx);
-        system->hip_ctx = NULL;
-    }
-    if (!system->hip_ctx) {
-        /* head-room for insertions: a context is sized once, like the reference's pair-list growth steps */
-        system->hip_capacity = system->natoms + (system->ensemble == ENSEMBLE_UVT ? system->natoms / 2 + 1024 : 0);
-        if (mpmc_hip_create(&system->hip_ctx, system->hip_device, system->hip_capacity)) {
-            hip_fail("create");
-            return NAN; /* mc.c treats a non-finite energy as a reject (mc.c:315-318) */
-        }
-        system->hip_dirty_all = 1;
-    }
-    int need_upload = system->hip_dirty_all || system->last_volume != system->pbc->volume;
+    int need_upload = !system->hip_ctx || system->hip_dirty_all || system->last_volume != system->pbc->volume;
     if (!need_upload) {
-        const int rc = sync_device(system);
+        const int rc = sync_device(system); /* also counts the atoms (reference countNatoms(), energy.c:36-46) */
         if (rc < 0) return NAN;
         need_upload = rc;
     }
     if (need_upload) {
+        system->natoms = countNatoms(system);
+        if (system->hip_ctx && system->natoms > system->hip_capacity) { /* uvt grew past the context */
+            mpmc_hip_destroy(system->hip_ctx);
+            system->hip_ctx = NULL;
+        }
+        if (!system->hip_ctx) {
+            /* head-room for insertions: a context is sized once, like the reference's pair-list growth steps */
+            system->hip_capacity = system->natoms + (system->ensemble == ENSEMBLE_UVT ? system->natoms / 2 + 1024 : 0);
+            if (mpmc_hip_create(&system->hip_ctx, system->hip_device, system->hip_capacity)) {
+                hip_fail("create");
+                return NAN; /* mc.c treats a non-finite energy as a reject (mc.c:315-318) */
+            }
+        }
         if (system->last_volume != system->pbc->volume) pbc(system);
         if (full_upload(system)) return NAN;
     }
