@@ -125,6 +125,9 @@ def main():
     if os.environ.get("MPMC_OVERLAP"):
         chain.energy()
         chain.set_option("overlap_streams", int(os.environ["MPMC_OVERLAP"]))
+    if os.environ.get("MPMC_SIDE_AFTER"):
+        chain.energy()
+        chain.set_option("side_after", int(os.environ["MPMC_SIDE_AFTER"]))
     if os.environ.get("MPMC_STEP_GRAPH"):
         chain.energy()
         chain.set_option("step_graph", int(os.environ["MPMC_STEP_GRAPH"]))
