@@ -112,6 +112,7 @@ struct SweepView {
     size_t Ccap = 0;       // double2 elements
     bool C_valid = false;
     bool pos_valid = false;  // px/py/pz/palpha/pflags match the configuration (moves are applied to both copies)
+    unsigned long long ranked_call = 0;  // view 1: the energy() call that last walked (and so maintained) it
     int *d_slot = nullptr;  // device copy of slot_of_atom (padded with -1)
     std::vector<int> slot_of_atom;  // atom index -> view slot, -1 if not in the view
     double *es = nullptr, *mu0 = nullptr, *mu1 = nullptr, *munew = nullptr, *y = nullptr, *efind = nullptr,
@@ -175,7 +176,8 @@ struct mpmc_hip_ctx {
     bool pair_part_valid = false;   // d_pairpart holds the tile partials of the configuration before the pending moves
     bool field_part_valid = false;  // same for d_fieldpart (real-space static field)
     int field_key = -1;             // mode / chunking the resident field partials were made with
-    double *d_lrcpart = nullptr;    // scratch of the (cached) long-range correction
+    double *d_lrcpart = nullptr;    // tile partials of the (cached) long-range correction
+    double *d_rankpart = nullptr;   // scratch of the ranking metric (per-tile minima)
     DirtyBlocks dirty_blocks;       // of the energy() call in progress
     bool in_flight = false;         // between energy_begin() and energy_end()
     // ---- grand-canonical edits (insert_molecule / remove_molecule): c->n is the number of atom SLOTS in use,
@@ -464,6 +466,7 @@ extern "C" int mpmc_hip_create(mpmc_hip_ctx **out, int device, int max_atoms) {
     const size_t ntile = np / 64;
     DALLOC(c->d_pairpart, ntile * ntile * kPairChannels, double);
     DALLOC(c->d_lrcpart, ntile * ntile, double);
+    DALLOC(c->d_rankpart, ntile * ntile, double);
     const size_t nchunk_max = std::max<size_t>(1, np / 64) + 16;  // + k-chunk slots of the Ewald field
     DALLOC(c->d_fieldpart, nchunk_max * 3 * np, double);
     DALLOC(c->d_res, R_COUNT, double);
@@ -505,7 +508,7 @@ extern "C" void mpmc_hip_destroy(mpmc_hip_ctx *c) {
     void *dptrs[] = {c->d_x,   c->d_y,     c->d_z,     c->d_q,    c->d_alpha, c->d_eps,      c->d_sig,
                      c->d_molmass, c->d_mol, c->d_flags, c->d_es, c->d_mu,    c->d_efind,    c->d_efchg,
                      c->d_tmp3, c->d_rank, c->d_errmax, c->d_pairpart, c->d_fieldpart, c->d_perk, c->d_kvec,
-                     c->d_res,  c->d_kvecf, c->d_sf, c->d_lrcpart};
+                     c->d_res,  c->d_kvecf, c->d_sf, c->d_lrcpart, c->d_rankpart};
     for (void *p : dptrs)
         if (p) hipFree(p);
     for (SweepView &v : c->view) {

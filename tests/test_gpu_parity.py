@@ -307,6 +307,44 @@ def test_incremental_updates_are_bit_identical_to_full_recomputation(pair_coeffi
         e.close()
 
 
+def test_ranked_gauss_seidel_chain_keeps_its_view_incrementally():
+    """Production flags (Wolf field, ranked Gauss-Seidel, Palmo, gamma 1.03): the ranked view's matrix stays
+    resident while the ranked walk does not change and only the moved atoms' rows / columns are rewritten;
+    the static-field and pair partials persist too.  A chain of moves must give bitwise the energies of an
+    engine that rebuilds everything every step, and track the oracle."""
+    s = synth.s_pol(640)
+    p = dict(synth.FLAGS_POL_PRODUCTION)
+    rng = np.random.default_rng(3)
+    engs = []
+    for inc in (1, 0):
+        e = engine.Engine(640)
+        e.load_system(s, p)
+        e.set_option("incremental_amatrix", inc)
+        e.set_option("incremental_pairs", inc)
+        engs.append(e)
+    pos = s["pos"].copy()
+    for step in range(10):
+        first = 5 * int(rng.integers(0, 640 // 5))
+        new = pos[first:first + 5] + rng.normal(scale=0.15, size=3)
+        accept = step % 3 != 1
+        got = []
+        for e in engs:
+            e.update_atoms(first, new)
+            got.append(e.energy())
+            if not accept:
+                e.update_atoms(first, pos[first:first + 5])
+        for key in ("energy", "polarization_energy", "rd_energy", "coulombic_energy"):
+            assert got[0][key] == got[1][key], (step, key)
+        s2 = dict(s)
+        s2["pos"] = pos.copy()
+        s2["pos"][first:first + 5] = new
+        check_energies(got[0], oracle.energy(s2, p))
+        if accept:
+            pos[first:first + 5] = new
+    for e in engs:
+        e.close()
+
+
 def test_step_graph_replay_is_bit_identical_to_direct_launches():
     """Option step_graph: a steady-state MC step is captured once as a HIP graph and replayed with only
     the moved-atom arguments refreshed.  Same kernels, same order of every sum: energies must equal the
