@@ -45,6 +45,28 @@ def test_host_chain_tracks_the_oracle():
     h.close()
 
 
+def test_long_chain_on_the_headline_box_has_no_drift():
+    """600 MC steps on the 4096-atom PCN-61 box, everything maintained incrementally (pair coefficients,
+    pair / field tile partials, view coordinates): the energy the chain carries at the end must be, bit for
+    bit, what a fresh context computes from scratch for the chain's final configuration."""
+    s = dict(np.load(os.path.join(ROOT, "tests", "golden", "pcn61_bssp_4096.npz")))
+    p = dict(temperature=77.0, polarization=1, polar_damp=2.1304, polar_max_iter=4, pbc_cutoff=8.0,
+             feynman_hibbs=1, feynman_hibbs_order=4)
+    h = host.HostSystem(s, p, seed=5)
+    acc = h.mc_steps(600)
+    assert 0 < acc < 600
+    o = h.observables()
+    s2 = dict(s)
+    s2["pos"] = h.positions()
+    eng = engine.Engine(len(s["charge"]))
+    eng.load_system(s2, p)
+    fresh = eng.energy()
+    for key in ("energy", "rd_energy", "coulombic_energy", "polarization_energy"):
+        assert o[key] == fresh[key], key
+    eng.close()
+    h.close()
+
+
 def test_same_seed_same_chain():
     s = synth.s_pol(160)
     p = dict(synth.FLAGS_POL_JACOBI)
