@@ -446,7 +446,7 @@ __global__ __launch_bounds__(64) void apply_edits_kernel(EditList e, EditTargets
             t.pz[s] = e.z[k];
         }
         t.palpha[s] = e.alpha[k];
-        t.pflags[s] = e.flags[k];
+        t.pflags[s] = (e.alpha[k] != 0.0) ? e.flags[k] : 0;  // a view slot only counts while it holds a polarizable site
     }
 }
 
