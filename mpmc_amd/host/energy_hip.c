@@ -197,6 +197,10 @@ static int sync_device(system_t *system) {
             continue;
         }
         sh->seen[s] = sh->epoch;
+        if (m->frozen) { /* frozen molecules are never moved (mc_moves.c picks among the others): no comparison */
+            natoms += sh->count[s];
+            continue;
+        }
         int k = 0, moved = 0;
         for (atom_t *a = m->atoms; a; a = a->next, k++)
             moved |= (a->pos[0] != sh->x[s + k]) | (a->pos[1] != sh->y[s + k]) | (a->pos[2] != sh->z[s + k]);

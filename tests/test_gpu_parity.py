@@ -166,6 +166,30 @@ def test_triclinic_box_polarizable(flags):
     eng.close()
 
 
+def test_half_box_ties_use_one_image_everywhere():
+    """Atoms exactly half a box apart (framework atoms on special positions do this): both images are
+    equidistant, rint() decides, and the dipole tensor depends on which one is taken.  The sweep rebuilds the
+    displacement itself, so it must take the image the coefficients were built with -- and both must take the
+    reference's.  A 4 x 4 x 4 lattice with spacing L/4 in a cubic and in a sheared cell (every pair along an
+    axis at distance L/2 is a tie), slightly polarizable and charged so that nothing cancels by symmetry."""
+    n, L = 64, 12.0
+    g = np.arange(4) * (L / 4)
+    frac = np.array([[x, y, z] for x in g for y in g for z in g])
+    rng = np.random.default_rng(2)
+    for basis in (np.diag([L, L, L]), np.array([[L, 0, 0], [0.25 * L, L, 0], [0.0, 0.5 * L, L]])):
+        pos = (frac / L) @ basis  # lattice points of the cell: ties are exact in fractional coordinates
+        s = dict(pos=pos, charge=rng.normal(scale=60.0, size=n), alpha=rng.uniform(0.3, 1.2, size=n),
+                 epsilon=np.full(n, 10.0), sigma=np.full(n, 2.5), mass=np.full(n, 4.0),
+                 molecule=np.arange(n, dtype=np.int32), frozen=np.zeros(n, dtype=np.int32), basis=basis)
+        s["charge"] -= s["charge"].mean()
+        p = dict(temperature=77.0, polarization=1, polar_damp=2.1304, polar_max_iter=5, polar_palmo=1)
+        got = run_engine(s, p, vectors=True)
+        want = oracle.energy(s, p, want_vectors=True)
+        check_energies(got, want)
+        assert np.abs(got["mu"] - want["mu"]).max() <= 1e-10 * np.abs(want["mu"]).max()
+        assert np.abs(got["ef_static"] - want["ef_static"]).max() <= 1e-10 * np.abs(want["ef_static"]).max()
+
+
 POLAR_VARIANTS = {
     "jacobi10": dict(polar_max_iter=10),
     "jacobi_sor": dict(polar_max_iter=6, polar_sor=1, polar_gamma=0.8),
