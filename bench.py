@@ -90,6 +90,9 @@ def main():
     ap.add_argument("--corrtime", type=int, default=10)
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--walkers-per-gpu", type=int, default=1,
+                    help="independent walkers driven by each rank on its GPU, interleaved (default 1 = the headline "
+                         "definition: one Markov chain per GPU); value counts the steps of all of them")
     ap.add_argument("--uvt", action="store_true",
                     help="grand-canonical chain (insert / remove / displace) with the flags of the reference's "
                          "3_PCN61/iter.inp (insert_probability 0.666, pressure 70 atm as the fugacity) instead of NVT")
@@ -119,9 +122,13 @@ def main():
     n = len(system["charge"])
     # host control stays in C: system_t + energy() + the NVT chain of mpmc_amd/host/ drive the engine through the C ABI
     extra = {"ensemble": "uvt", "insert_probability": 0.666, "pressure": 70.0} if args.uvt else None
-    chain = host.HostSystem(system, flags, device=local_rank, seed=args.seed + rank, extra=extra)
+    W = max(1, args.walkers_per_gpu)
+    chains = [host.HostSystem(system, flags, device=local_rank, seed=args.seed + rank * W + w, extra=extra)
+              for w in range(W)]
+    chain = chains[0]
     avg = WalkerAverages(dist=dist, device=dev)
-    chain.energy()  # creates the device context, uploads the configuration
+    for ch in chains:
+        ch.energy()  # creates the device context, uploads the configuration
     if os.environ.get("MPMC_OVERLAP"):
         chain.energy()
         chain.set_option("overlap_streams", int(os.environ["MPMC_OVERLAP"]))
@@ -149,15 +156,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    pool = None
+    if W > 1 and not os.environ.get("MPMC_WALKERS_ONE_THREAD"):
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(W)
+
     def run(nsteps):
         done = 0
         while done < nsteps:
             k = min(args.corrtime, nsteps - done)
-            acc = chain.mc_steps(k)
+            if W == 1:
+                acc = chain.mc_steps(k)
+            elif pool is None:
+                acc = host.mc_steps_multi(chains, k)  # one host thread feeds all walkers
+            else:
+                acc = sum(pool.map(lambda ch: ch.mc_steps(k), chains))  # one host thread per walker (ctypes drops the GIL)
             done += k
-            o = chain.observables()
-            avg.add(o["energy"], o["rd_energy"], o["coulombic_energy"], o["polarization_energy"],
-                    o["polar_iterations"], acc / float(k))
+            for ch in chains:
+                o = ch.observables()
+                avg.add(o["energy"], o["rd_energy"], o["coulombic_energy"], o["polarization_energy"],
+                        o["polar_iterations"], acc / float(k * W))
             # walker averaging every corrtime (reference mc.c:417-432: MPI_Gather of observables)
             avg.reduce()
 
@@ -185,7 +203,7 @@ def main():
     elapsed = float(tmax.item())
 
     if rank == 0:
-        value = world * args.steps / elapsed
+        value = world * W * args.steps / elapsed
         # event pairs bracket the sweep kernel on every 8th call of the timed region; an EMPTY pair recorded on
         # the same calls measures what the two event records themselves add, and is subtracted
         sweep_raw_ms = acc["sweep_ms"] / max(1, acc["sweep_count"])
@@ -235,8 +253,8 @@ def main():
             "data": "synthetic" if args.workload != "pcn61_4096" else
                     "reference sample geometry (PCN-61 cell carved from sample_configs_gpu/3_PCN61/input.pdb), "
                     "random MC moves",
-            "config": {"workload": label + (" [UVT: insert/remove/displace]" if args.uvt else ""), "n_atoms": n, "n_polarizable": n_pol, "walkers": world, "corrtime": args.corrtime,
-                       "parallelism": "%d independent walkers, 1 per GPU" % world},
+            "config": {"workload": label + (" [UVT: insert/remove/displace]" if args.uvt else ""), "n_atoms": n, "n_polarizable": n_pol, "walkers": world * W, "corrtime": args.corrtime,
+                       "parallelism": "%d independent walkers, %d per GPU" % (world * W, W)},
             "roofline": {"kernel": kernel_name + " (Thole field / dipole sweep)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -259,7 +277,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(system, flags)
         print(json.dumps(out))
-    chain.close()
+    for ch in chains:
+        ch.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -41,6 +41,8 @@ def load():
     lib.host_natoms.argtypes = [vp]
     lib.host_get_system.argtypes = [vp] * 9
     lib.host_seed.argtypes = [vp, C.c_uint]
+    lib.host_mc_steps_multi.argtypes = [C.POINTER(vp), C.c_int, C.c_int]
+    lib.host_mc_steps_multi.restype = C.c_int
     lib.host_get_rand.argtypes = [vp]
     lib.host_get_rand.restype = C.c_double
     lib.energy.argtypes = [vp]
@@ -73,6 +75,17 @@ def config_text(flags, extra=None):
     for k, v in (extra or {}).items():
         lines.append("%s %s" % (k, v))
     return "\n".join(lines) + "\n"
+
+
+def mc_steps_multi(walkers, nsteps):
+    """Advance several HostSystem walkers together (one process, interleaved on the device): every walker takes
+    `nsteps` steps exactly as it would alone.  Returns the number of accepted moves over all walkers."""
+    lib = walkers[0].lib
+    arr = (C.c_void_p * len(walkers))(*[w.ptr for w in walkers])
+    acc = lib.host_mc_steps_multi(arr, len(walkers), int(nsteps))
+    if acc < 0:
+        raise engine.EngineError(engine.load().mpmc_hip_last_error().decode())
+    return acc
 
 
 class HostSystem:

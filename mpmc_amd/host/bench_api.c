@@ -2,6 +2,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <math.h>
 #include "mpmc_host.h"
 
 int hip_download_dipoles(system_t *system);
@@ -61,6 +62,55 @@ int host_mc_steps(system_t *system, int nsteps) {
         }
     }
     return system->nodestats->accept - acc0;
+}
+
+/* The same chain for W walkers at once (independent systems, each with its own engine context, possibly on one
+ * device): the trial moves of all walkers are enqueued before the first result is collected, so one walker's
+ * launch gaps and host work are filled with another's kernels.  Every walker takes exactly the steps it would
+ * take alone -- its random numbers, decisions and energies do not depend on its neighbours. */
+int host_mc_steps_multi(system_t **systems, int nwalkers, int nsteps) {
+    int accepted = 0;
+    for (int w = 0; w < nwalkers; w++) {
+        system_t *system = systems[w];
+        if (system->step == 0 && system->avg_observables->counter == 0.0) {
+            system->observables->volume = system->pbc->volume;
+            double e = energy(system);
+            if (e != e) return -1;
+            checkpoint(system);
+            system->avg_observables->counter = 1.0;
+        }
+    }
+    double initial[64];
+    int ok[64];
+    if (nwalkers > 64) return -1;
+    for (int k = 0; k < nsteps; k++) {
+        for (int w = 0; w < nwalkers; w++) {
+            system_t *system = systems[w];
+            ++system->step;
+            initial[w] = system->observables->energy;
+            make_move(system);
+            ok[w] = (energy_begin(system) == 0);
+        }
+        for (int w = 0; w < nwalkers; w++) {
+            system_t *system = systems[w];
+            const double final_energy = ok[w] ? energy_end(system) : NAN;
+            if (final_energy != final_energy || final_energy - final_energy != 0.0) {
+                system->observables->energy = MAXVALUE;
+                system->nodestats->boltzmann_factor = 0;
+            } else
+                boltzmann_factor(system, initial[w], final_energy);
+            if ((get_rand(system) < system->nodestats->boltzmann_factor) && (system->iter_success == 0)) {
+                checkpoint(system);
+                ++system->nodestats->accept;
+                ++accepted;
+            } else {
+                system->iter_success = 0;
+                restore(system);
+                ++system->nodestats->reject;
+            }
+        }
+    }
+    return accepted;
 }
 
 void host_set_device(system_t *system, int device) { system->hip_device = device; }

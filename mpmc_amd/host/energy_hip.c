@@ -253,12 +253,13 @@ static int sync_device(system_t *system) {
     return 0;
 }
 
-double energy(system_t *system) {
+/* First half of energy(): bring the device in line with the lists and enqueue the evaluation. */
+int energy_begin(system_t *system) {
     const double t0 = now_s();
     int need_upload = !system->hip_ctx || system->hip_dirty_all || system->last_volume != system->pbc->volume;
     if (!need_upload) {
         const int rc = sync_device(system); /* also counts the atoms (reference countNatoms(), energy.c:36-46) */
-        if (rc < 0) return NAN;
+        if (rc < 0) return -1;
         need_upload = rc;
     }
     if (need_upload) {
@@ -270,32 +271,32 @@ double energy(system_t *system) {
         if (!system->hip_ctx) {
             /* head-room for insertions: a context is sized once, like the reference's pair-list growth steps */
             system->hip_capacity = system->natoms + (system->ensemble == ENSEMBLE_UVT ? system->natoms / 2 + 1024 : 0);
-            if (mpmc_hip_create(&system->hip_ctx, system->hip_device, system->hip_capacity)) {
-                hip_fail("create");
-                return NAN; /* mc.c treats a non-finite energy as a reject (mc.c:315-318) */
-            }
+            if (mpmc_hip_create(&system->hip_ctx, system->hip_device, system->hip_capacity)) return hip_fail("create");
         }
         if (system->last_volume != system->pbc->volume) pbc(system);
-        if (full_upload(system)) return NAN;
+        if (full_upload(system)) return -1;
     }
-
-    /* the device works while the host does the bookkeeping that does not need the energies */
-    mpmc_hip_result r;
     const double t1 = now_s();
-    if (mpmc_hip_energy_begin(system->hip_ctx)) {
-        hip_fail("energy");
-        return NAN;
-    }
+    if (mpmc_hip_energy_begin(system->hip_ctx)) return hip_fail("energy");
+    g_prof[0] += t1 - t0;
+    g_prof[1] += now_s() - t1;
+    return 0;
+}
+
+/* Second half: the bookkeeping that does not need the energies runs while the device works, then the result
+ * is collected into system->observables. */
+double energy_end(system_t *system) {
     const double t2 = now_s();
     update_com(system->molecules); /* pairs.c:331 */
     countN(system);
     const double t3 = now_s();
+    mpmc_hip_result r;
     if (mpmc_hip_energy_end(system->hip_ctx, &r)) {
         hip_fail("energy");
         return NAN;
     }
     const double t4 = now_s();
-    g_prof[0] += t1 - t0; g_prof[1] += t2 - t1; g_prof[2] += t3 - t2; g_prof[3] += t4 - t3;
+    g_prof[2] += t3 - t2; g_prof[3] += t4 - t3;
     g_prof_calls++;
     if (system->hip_timing) {
         mpmc_hip_timings t;
@@ -320,6 +321,11 @@ double energy(system_t *system) {
     o->NU = o->N * o->energy;          /* energy.c:219 */
     system->last_volume = system->pbc->volume; /* energy.c:222 */
     return o->energy;
+}
+
+double energy(system_t *system) {
+    if (energy_begin(system)) return NAN; /* mc.c treats a non-finite energy as a reject (mc.c:315-318) */
+    return energy_end(system);
 }
 
 /* atom->mu / ef_static / ef_induced as polar() leaves them; called where the reference reads them

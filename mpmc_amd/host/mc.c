@@ -12,25 +12,27 @@
 #include "mpmc_host.h"
 
 /* ---- std::mt19937 + std::uniform_real_distribution<double>(0,1) as libstdc++ evaluates it:
- * generate_canonical<double,53> draws two 32-bit words, sum = w0 + w1 * 2^32, result sum / 2^64. */
-static unsigned int mt[624];
-static int mti = 625;
-
-void seed_rng(unsigned int seed) {
+ * generate_canonical<double,53> draws two 32-bit words, sum = w0 + w1 * 2^32, result sum / 2^64.
+ * The generator state lives in the system_t (the reference has one per process = per walker; here one
+ * process may drive several walkers, each with its own stream of numbers). */
+void seed_rng(system_t *system, unsigned int seed) {
+    unsigned int *mt = system->rng_mt;
+    int mti;
     mt[0] = seed;
     for (mti = 1; mti < 624; mti++) mt[mti] = 1812433253u * (mt[mti - 1] ^ (mt[mti - 1] >> 30)) + (unsigned int)mti;
+    system->rng_mti = mti;
 }
 
-static unsigned int mt_next(void) {
-    if (mti >= 624) {
-        if (mti == 625) seed_rng(5489u);
+static unsigned int mt_next(system_t *system) {
+    unsigned int *mt = system->rng_mt;
+    if (system->rng_mti >= 624) {
         for (int k = 0; k < 624; k++) {
             unsigned int y = (mt[k] & 0x80000000u) | (mt[(k + 1) % 624] & 0x7fffffffu);
             mt[k] = mt[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
         }
-        mti = 0;
+        system->rng_mti = 0;
     }
-    unsigned int y = mt[mti++];
+    unsigned int y = mt[system->rng_mti++];
     y ^= (y >> 11);
     y ^= (y << 7) & 0x9d2c5680u;
     y ^= (y << 15) & 0xefc60000u;
@@ -42,7 +44,7 @@ double get_rand(system_t *system) {
     if (!system->rng_initialized) {
         system->rng_initialized = 1;
         if (system->preset_seeds_on)
-            seed_rng(system->preset_seeds);
+            seed_rng(system, system->preset_seeds);
         else {
             unsigned int s = 5489u;
             FILE *f = fopen("/dev/urandom", "rb");
@@ -50,12 +52,12 @@ double get_rand(system_t *system) {
                 if (fread(&s, sizeof(s), 1, f) != 1) s = 5489u;
                 fclose(f);
             }
-            seed_rng(s);
+            seed_rng(system, s);
         }
     }
     double sum = 0.0, tmp = 1.0;
     for (int k = 0; k < 2; k++) {
-        sum += (double)mt_next() * tmp;
+        sum += (double)mt_next(system) * tmp;
         tmp *= 4294967296.0;
     }
     double ret = sum / tmp;

@@ -100,6 +100,8 @@ typedef struct _system {
     int preset_seeds_on;
     unsigned int preset_seeds;
     int rng_initialized;
+    unsigned int rng_mt[624]; /* std::mt19937 state of this walker */
+    int rng_mti;
     /* energy options (reference keywords) */
     int rd_only, rd_lrc, feynman_hibbs, feynman_hibbs_order, wrapall, wolf;
     int ewald_alpha_set, ewald_kmax, polar_ewald_alpha_set;
@@ -140,6 +142,8 @@ void free_system(system_t *system);
 
 /* energy (reference src/energy/energy.c) */
 double energy(system_t *system);
+int energy_begin(system_t *system);  /* energy() in two halves, so that several walkers can share a process */
+double energy_end(system_t *system);
 int countNatoms(system_t *system);
 void update_com(molecule_t *molecules);
 
@@ -150,7 +154,7 @@ void restore(system_t *system);
 void make_move(system_t *system);
 void boltzmann_factor(system_t *system, double initial_energy, double final_energy);
 double get_rand(system_t *system);
-void seed_rng(unsigned int seed);
+void seed_rng(system_t *system, unsigned int seed);
 molecule_t *copy_molecule(system_t *system, molecule_t *src);
 void free_molecule(system_t *system, molecule_t *molecule);
 void translate(system_t *system, molecule_t *molecule, pbc_t *pbc, double scale);

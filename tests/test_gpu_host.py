@@ -45,6 +45,30 @@ def test_host_chain_tracks_the_oracle():
     h.close()
 
 
+def test_interleaved_walkers_take_the_steps_they_would_take_alone():
+    """host_mc_steps_multi drives several walkers from one process (their kernels interleave on the device).
+    Each walker has its own random-number stream and engine context: its trajectory must be, bit for bit, the
+    one it produces when it runs alone."""
+    s = synth.s_pol(320)
+    p = dict(synth.FLAGS_POL_JACOBI, polar_max_iter=4)
+    seeds = (7, 8, 9)
+    alone = []
+    for sd in seeds:
+        h = host.HostSystem(s, p, seed=sd, move_factor=0.05, rot_factor=0.05)
+        h.mc_steps(40)
+        alone.append((h.observables()["energy"], h.observables()["accept"], h.positions()))
+        h.close()
+    walkers = [host.HostSystem(s, p, seed=sd, move_factor=0.05, rot_factor=0.05) for sd in seeds]
+    total = 0
+    for _ in range(4):
+        total += host.mc_steps_multi(walkers, 10)
+    assert total == sum(a[1] for a in alone)
+    for w, a in zip(walkers, alone):
+        o = w.observables()
+        assert o["energy"] == a[0] and o["accept"] == a[1] and np.array_equal(w.positions(), a[2])
+        w.close()
+
+
 def test_long_chain_on_the_headline_box_has_no_drift():
     """600 MC steps on the 4096-atom PCN-61 box, everything maintained incrementally (pair coefficients,
     pair / field tile partials, view coordinates): the energy the chain carries at the end must be, bit for
