@@ -183,6 +183,9 @@ def main():
     # timed region: HIP events around the dominant (sweep) kernel only -- every event pair costs a few
     # microseconds of stream time, so the per-class breakdown is taken in a separate, untimed pass below
     chain.set_option("timing", 1)
+    # sampled calls cost ~80 us extra (event pairs on the stream + reading them back): every 32nd call, or every
+    # 4th in short runs so that a handful of sweeps is still sampled
+    chain.set_option("timing_interval", 32 if args.steps >= 128 else 4)
     chain.enable_timing(True)
     sync()
     t0 = time.perf_counter()
@@ -204,7 +207,7 @@ def main():
 
     if rank == 0:
         value = world * W * args.steps / elapsed
-        # event pairs bracket the sweep kernel on every 8th call of the timed region; an EMPTY pair recorded on
+        # event pairs bracket the sweep kernel on every 32nd call of the timed region (every 4th in runs < 128 steps); an EMPTY pair recorded on
         # the same calls measures what the two event records themselves add, and is subtracted
         sweep_raw_ms = acc["sweep_ms"] / max(1, acc["sweep_count"])
         event_pair_ms = acc["event_pair_ms"] / max(1, acc["event_pair_count"])

@@ -123,8 +123,8 @@ void mpmc_hip_destroy(mpmc_hip_ctx *ctx);
  *                          polarization chain;
  *   "symmetric_sweep"     (default 1; with pair_coefficients = 0): sweeps read only the upper triangle of A and
  *                          use every element for both products; 0 = full-matrix sweep; 2 = also below 2048 atoms;
- *   "timing"              (default 1): 0 = record no HIP events; 1 = time the sweep kernels of every 8th
- *                          call (plus an empty event pair for calibration); 2 = time every kernel class of every
+ *   "timing"              (default 1): 0 = record no HIP events; 1 = time the sweep kernels of every 32nd
+ *                          call ("timing_interval" changes the 32; plus an empty event pair for calibration); 2 = time every kernel class of every
  *                          call (each event pair costs ~5 microseconds of stream time);
  *   "persistent_gs"       (default 1): Gauss-Seidel lower-triangle phase as one persistent kernel
  *                          (spine + owner workgroups); 0 = two launches per 64-atom block;

@@ -204,6 +204,7 @@ struct mpmc_hip_ctx {
     bool box_ortho = false; // every off-diagonal basis entry is exactly zero
     int num_cus = 256;
     int opt_timing = 1;    // 0: no events, 1: sweep kernels + total only, 2: every kernel class
+    int opt_timing_interval = 32;  // timing 1 / -1: every how many calls
     int opt_sym_mode = 0;  // bit 0: alternate sweep direction, bit 1: default-policy loads
     int sweep_parity = 0;
     int *h_dirty = nullptr;         // pinned staging for dirty slots
@@ -285,10 +286,12 @@ static DevBox dev_box(const mpmc_hip_ctx *c) {
 
 static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-// timing 1: events around the sweep kernels of every 8th call (an event pair costs ~4 us of stream time,
-// and a timed call is enqueued launch by launch instead of replaying the step graph); 2: every call
+// timing 1: events around the sweep kernels of every 32nd call (an event pair costs ~5 us of stream time and
+// reading the events back stalls the host: sampling every 8th call cost 10 % of the step rate); 2: every call;
+// -1: only the first-launch / last-kernel pair of every 32nd call (length of the device chain)
 static inline bool is_timed_call(const mpmc_hip_ctx *c) {
-    return c->opt_timing >= 2 || (c->opt_timing == 1 && (c->energy_calls & 7ull) == 0ull);
+    return c->opt_timing >= 2 || ((c->opt_timing == 1 || c->opt_timing == -1) &&
+                                 (c->energy_calls % (unsigned long long)c->opt_timing_interval) == 0ull);
 }
 
 // Launch of one of the GraphSlotId kernels: a plain launch (which stream capture records), or, while a
@@ -326,7 +329,8 @@ struct ScopedTimer {
     bool on;
     ScopedTimer(mpmc_hip_ctx *ctx, int cls, hipStream_t st = nullptr) : c(ctx), s(st ? st : ctx->stream), on(false) {
         const bool wanted = c->graph_mode == GM_DIRECT &&
-                            (c->opt_timing >= 2 || ((cls == T_SWEEP || cls == T_EVPAIR) && is_timed_call(c)));
+                            (c->opt_timing >= 2 ||
+                             (c->opt_timing == 1 && (cls == T_SWEEP || cls == T_EVPAIR) && is_timed_call(c)));
         if (wanted && c->ev_next + 2 <= c->ev_pool.size()) {
             r.cls = cls;
             r.a = c->ev_pool[c->ev_next++];
@@ -348,6 +352,10 @@ extern "C" int mpmc_hip_set_option(mpmc_hip_ctx *c, const char *name, int value)
     ++c->config_rev;
     if (!strcmp(name, "step_graph")) {
         c->opt_graph = value;
+        return 0;
+    }
+    if (!strcmp(name, "timing_interval")) {
+        c->opt_timing_interval = std::max(1, value);
         return 0;
     }
     if (!strcmp(name, "side_after")) {
