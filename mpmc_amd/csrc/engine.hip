@@ -2,12 +2,14 @@
 // orchestration for one energy() evaluation, and the extern "C" ABI of include/mpmc_hip.h.
 //
 // Control flow of mpmc_hip_energy() mirrors reference src/energy/energy.c:67-226:
-//   [polar]  rank metric -> A build -> static field -> SCF sweeps -> (Palmo) -> U_pol
-//   [lj]     fused pair kernel (LJ + FH) + cached long-range correction
-//   [es]     real-space part in the same pair kernel, reciprocal kernel, self term
-// All on one HIP stream per context; the only host<->device traffic per call is the moved
-// molecule's coordinates in and a 32-double result record out (the reference plugin re-allocated
-// and re-uploaded everything per call, polar_cuda_pcg.cu:221-401).
+//   [polar]  rank metric -> dipole-tensor data (pair coefficients, or the expanded A matrix for the
+//            Gauss-Seidel modes) -> static field -> SCF sweeps -> (Palmo) -> U_pol      main stream
+//   [lj]     fused pair kernel (LJ + FH) + cached long-range correction                  side stream
+//   [es]     real-space part in the same pair kernel, reciprocal kernel, self term       side stream
+// Everything pairwise is resident and updated incrementally after a move (coefficients, tile partial
+// sums of the pair / field / LRC kernels); the only host<->device traffic per call is the moved
+// molecule's coordinates in (kernel arguments) and a 16-double result record out (mapped host memory).
+// The reference plugin re-allocated and re-uploaded everything per call (polar_cuda_pcg.cu:221-401).
 #include "../../include/mpmc_hip.h"
 
 #include <dlfcn.h>

@@ -1,8 +1,8 @@
-// kernels_polar.h -- Thole polarization on gfx950: static field, A-matrix build,
-// dipole sweeps (Jacobi / SOR / ESOR; Gauss-Seidel lives in kernels_gs.h), Palmo-Krimm
-// contraction, polarization energy.
+// kernels_polar.h -- Thole polarization on gfx950: static field, the EXPANDED A matrix (build, incremental
+// update, full-matrix sweep; used by the Gauss-Seidel modes and as an A/B path -- the default Jacobi-type
+// sweeps run on pair coefficients, kernels_coef.h), view set-up, move / edit application, polarization energy.
 //
-// Memory layout (HBM):
+// Memory layout of the expanded matrix (HBM):
 //   A        : (3*npad) x (3*npad) fp64, row-major, ONE allocation (the reference keeps 3N
 //              separately malloc'd rows, thole_matrix.c:172-178).  Row 3i+p, column 3j+q holds
 //              T_ij[p][q]; diagonal blocks hold 1/alpha_i (1e40 for alpha = 0), as the reference.
