@@ -84,8 +84,8 @@ def cpu_baseline(system, flags, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--workload", default="pcn61_4096")
     ap.add_argument("--corrtime", type=int, default=10)
     ap.add_argument("--seed", type=int, default=1234)
