@@ -128,13 +128,13 @@ struct SweepView {
 
 // The kernels of one steady-state MC step whose arguments change from step to step; every other node of
 // the captured graph is replayed as it was.
-enum GraphSlotId { GS_MOVES = 0, GS_COEF, GS_FIELD, GS_PAIR, GS_PUBLISH, GS_NSLOT };
+enum GraphSlotId { GS_MOVES = 0, GS_COEF, GS_FIELD, GS_PAIR, GS_RECIP, GS_PUBLISH, GS_NSLOT };
 enum GraphMode { GM_DIRECT = 0, GM_CAPTURE = 1, GM_UPDATE = 2 };
 struct StepGraph {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
-    void *func[GS_NSLOT] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipGraphNode_t node[GS_NSLOT] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    void *func[GS_NSLOT] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipGraphNode_t node[GS_NSLOT] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool valid = false;
     unsigned long long rev = 0;  // config_rev it was captured under
     // what the captured call left in the context besides device work
@@ -176,9 +176,13 @@ struct mpmc_hip_ctx {
     int opt_pair_coef = 1;  // Jacobi/Palmo sweeps on pair coefficients (0: on the expanded A matrix)
     int opt_incremental_pairs = 1;  // LJ/Ewald-real and static-field tile partials persist between calls
     bool pair_part_valid = false;   // d_pairpart holds the tile partials of the configuration before the pending moves
+    bool pair_part_valid_before = false;  // its value when the energy() call in progress started (after collect_dirty_blocks)
     bool field_part_valid = false;  // same for d_fieldpart (real-space static field)
     int field_key = -1;             // mode / chunking the resident field partials were made with
     double *d_lrcpart = nullptr;    // tile partials of the (cached) long-range correction
+    double2 *d_sfpart = nullptr;    // [block][nk] partial structure factors of the reciprocal-space sum
+    size_t sfpart_cap = 0;
+    bool recip_part_valid = false;
     double *d_rankpart = nullptr;   // scratch of the ranking metric (per-tile minima)
     DirtyBlocks dirty_blocks;       // of the energy() call in progress
     bool in_flight = false;         // between energy_begin() and energy_end()
@@ -217,7 +221,6 @@ struct mpmc_hip_ctx {
     // scratch
     double *d_pairpart = nullptr;   // [ntile*ntile][4]
     double *d_fieldpart = nullptr;  // [nchunk][3][npad]
-    double *d_perk = nullptr;       // [nk]
     KVec *d_kvec = nullptr;
     int nk = 0;
     KVecF *d_kvecf = nullptr;  // k list weighted with polar_ewald_alpha (Ewald static field)
@@ -517,8 +520,8 @@ extern "C" void mpmc_hip_destroy(mpmc_hip_ctx *c) {
     if (c->stream2) hipStreamSynchronize(c->stream2);
     void *dptrs[] = {c->d_x,   c->d_y,     c->d_z,     c->d_q,    c->d_alpha, c->d_eps,      c->d_sig,
                      c->d_molmass, c->d_mol, c->d_flags, c->d_es, c->d_mu,    c->d_efind,    c->d_efchg,
-                     c->d_tmp3, c->d_rank, c->d_errmax, c->d_pairpart, c->d_fieldpart, c->d_perk, c->d_kvec,
-                     c->d_res,  c->d_kvecf, c->d_sf, c->d_lrcpart, c->d_rankpart};
+                     c->d_tmp3, c->d_rank, c->d_errmax, c->d_pairpart, c->d_fieldpart, c->d_kvec,
+                     c->d_res,  c->d_kvecf, c->d_sf, c->d_lrcpart, c->d_rankpart, c->d_sfpart};
     for (void *p : dptrs)
         if (p) hipFree(p);
     for (SweepView &v : c->view) {
@@ -991,17 +994,13 @@ static int build_kvectors(mpmc_hip_ctx *c) {
         hipFree(c->d_kvec);
         c->d_kvec = nullptr;
     }
-    if (c->d_perk) {
-        hipFree(c->d_perk);
-        c->d_perk = nullptr;
-    }
     c->nk = (int)kv.size();
     if (c->nk > 0) {
         HIPCHK(hipMalloc((void **)&c->d_kvec, kv.size() * sizeof(KVec)));
-        HIPCHK(hipMalloc((void **)&c->d_perk, kv.size() * sizeof(double)));
         HIPCHK(hipMemcpy(c->d_kvec, kv.data(), kv.size() * sizeof(KVec), hipMemcpyHostToDevice));
     }
     c->kvec_valid = true;
+    c->recip_part_valid = false;
     return 0;
 }
 
@@ -1170,6 +1169,18 @@ static int launch_pair_kernel(mpmc_hip_ctx *c, const DevAtoms &a, const DevBox &
     return 0;
 }
 
+// partial structure factors of the moved atoms' blocks (graph slot GS_RECIP), or of all blocks
+static int launch_recip_partial(mpmc_hip_ctx *c, const DevAtoms &a, hipStream_t sb) {
+    const int ntile = c->npad / 64;
+    DirtyBlocks rsel = c->dirty_blocks;
+    if (!c->recip_part_valid || !c->pair_part_valid_before) rsel.n = 0;
+    if (c->recip_part_valid && c->pair_part_valid_before && c->dirty_atoms.empty()) return 0;  // nothing moved
+    HIPCHK(launch_slot(c, GS_RECIP, recip_partial_kernel, dim3((c->nk + 255) / 256, rsel.n > 0 ? rsel.n : ntile), dim3(256),
+                       sb, a, (const KVec *)c->d_kvec, c->nk, rsel, c->d_sfpart));
+    c->recip_part_valid = true;
+    return 0;
+}
+
 static int launch_publish(mpmc_hip_ctx *c, bool do_polar) {
     HIPCHK(launch_slot(c, GS_PUBLISH, publish_result_kernel, dim3(1), dim3(64), c->stream, c->d_res, c->h_res_dev,
                        (int)R_COUNT, (double)c->energy_calls, do_polar ? c->energy_part : (const double *)nullptr,
@@ -1201,6 +1212,7 @@ static void collect_dirty_blocks(mpmc_hip_ctx *c) {
     }
     for (int k = dirty_blocks.n; k < kMaxDirtyBlocks; ++k) dirty_blocks.blk[k] = 0;
     c->dirty_blocks = dirty_blocks;
+    c->pair_part_valid_before = c->pair_part_valid;  // false whenever the dirty-block list cannot be trusted
 }
 
 // One evaluation, launch by launch (also what stream capture records for the step graph).
@@ -1282,8 +1294,18 @@ static int enqueue_direct(mpmc_hip_ctx *c) {
         if (!P.rd_only && !P.wolf) {
             ScopedTimer t(c, T_RECIP, sb);
             if (c->nk > 0) {
-                hipLaunchKernelGGL(ewald_recip_kernel, dim3(c->nk), dim3(256), 0, sb, a, c->d_kvec, c->d_perk);
-                hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(kReduceThreads), 0, sb, c->d_perk, c->nk, 1,
+                // partial structure factors per 64-atom block stay resident; only the moved blocks are redone
+                const size_t need = (size_t)(c->max_npad / 64) * c->nk;
+                if (c->sfpart_cap < need) {
+                    if (c->d_sfpart) hipFree(c->d_sfpart);
+                    c->d_sfpart = nullptr;
+                    c->sfpart_cap = 0;
+                    HIPCHK(hipMalloc((void **)&c->d_sfpart, need * sizeof(double2)));
+                    c->sfpart_cap = need;
+                    c->recip_part_valid = false;
+                }
+                if (launch_recip_partial(c, a, sb)) return -1;
+                hipLaunchKernelGGL(recip_sum_kernel, dim3(1), dim3(1024), 0, sb, c->d_kvec, c->nk, ntile, c->d_sfpart,
                                    c->d_res + R_RECIP);
             } else {
                 HIPCHK(hipMemsetAsync(c->d_res + R_RECIP, 0, sizeof(double), sb));
@@ -1370,7 +1392,7 @@ static bool graph_finish_capture(mpmc_hip_ctx *c, hipGraph_t graph) {
     if (hipGraphGetNodes(g.graph, nullptr, &nn) != hipSuccess || nn == 0) return false;
     std::vector<hipGraphNode_t> nodes(nn);
     if (hipGraphGetNodes(g.graph, nodes.data(), &nn) != hipSuccess) return false;
-    int found[GS_NSLOT] = {0, 0, 0, 0, 0};
+    int found[GS_NSLOT] = {0, 0, 0, 0, 0, 0};
     for (hipGraphNode_t nd : nodes) {
         hipGraphNodeType ty;
         if (hipGraphNodeGetType(nd, &ty) != hipSuccess || ty != hipGraphNodeTypeKernel) continue;
@@ -1383,7 +1405,7 @@ static bool graph_finish_capture(mpmc_hip_ctx *c, hipGraph_t graph) {
             }
     }
     for (int s = 0; s < GS_NSLOT; ++s)
-        if (found[s] != 1) return false;
+        if (g.func[s] ? found[s] != 1 : found[s] != 0) return false;  // (a slot the step never launched has no node)
     return true;
 }
 
@@ -1398,6 +1420,7 @@ static int graph_step(mpmc_hip_ctx *c) {
     if (!rc) rc = setup_view(c, c->view[0], a, bx, true, true);
     if (!rc) rc = launch_field(c, a, bx);
     if (!rc) rc = launch_pair_kernel(c, a, bx, c->stream2);
+    if (!rc && c->sg.func[GS_RECIP]) rc = launch_recip_partial(c, a, c->stream2);
     c->energy_part = c->sg.energy_part;
     c->energy_nt = c->sg.energy_nt;
     if (!rc) rc = launch_publish(c, true);
@@ -1453,7 +1476,7 @@ extern "C" int mpmc_hip_energy_begin(mpmc_hip_ctx *c) {
             issued = true;
         } else if (++c->eligible_streak >= 3) {
             // third steady-state step in a row: record this one
-            graph_destroy(c);
+            graph_destroy(c);  // (also clears the slot table: a slot this step does not launch stays null)
             const MoveList saved = c->pending;
             bool ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
             if (ok) {

@@ -284,34 +284,6 @@ struct KVec {
     double kx, ky, kz, w;  // w = exp(-k^2/4a^2)/k^2
 };
 
-__global__ __launch_bounds__(256) void ewald_recip_kernel(DevAtoms a, const KVec *__restrict__ kv,
-                                                           double *__restrict__ per_k) {
-    const KVec k = kv[blockIdx.x];
-    double re = 0.0, im = 0.0;
-    for (int i = threadIdx.x; i < a.n; i += blockDim.x) {
-        const double q = a.q[i];
-        if ((a.flags[i] & kFrozen) || q == 0.0) continue;
-        const double ph = k.kx * a.x[i] + k.ky * a.y[i] + k.kz * a.z[i];
-        double s, c;
-        sincos(ph, &s, &c);
-        re += q * c;
-        im += q * s;
-    }
-    re = wave_sum(re);
-    im = wave_sum(im);
-    __shared__ double sre[4], sim[4];
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane == 0) {
-        sre[w] = re;
-        sim[w] = im;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const double R = (sre[0] + sre[1]) + (sre[2] + sre[3]);
-        const double Im = (sim[0] + sim[1]) + (sim[2] + sim[3]);
-        per_k[blockIdx.x] = k.w * (R * R + Im * Im);
-    }
-}
 
 // Point self term (coulombic.c:97-112): -alpha/sqrt(pi) * sum q^2 over non-frozen atoms.
 // One block; fixed-order reduction.
@@ -330,6 +302,67 @@ __global__ __launch_bounds__(256) void ewald_self_kernel(DevAtoms a, double ewal
 }
 
 // Fixed-order sum of `count` rows of `channels` doubles each: out[c] = sum_r in[r][c].
+// ---------------------------------------------------------------------------------------------
+// Reciprocal-space Ewald with resident partial structure factors: S_b(k) = sum over the atoms j of the 64-atom
+// block b of q_j e^{i k.r_j} (non-frozen, q != 0; coulombic.c:60-75) is kept per (block, k) between calls, and
+// after a move only the moved atoms' blocks are recomputed -- 64 sincos per k-vector instead of N.
+//   recip_partial_kernel: grid = (ceil(nk / 256), nblocks | sel.n); thread = k-vector, the block's atoms in LDS;
+//                         part layout [block][nk] (coalesced in k).
+//   recip_sum_kernel:     one workgroup; thread per k adds the block partials in block order, forms
+//                         w_k |S(k)|^2 and the fixed-order total (U_recip up to the 4 pi / V factor).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void recip_partial_kernel(DevAtoms a, const KVec *__restrict__ kv, int nk,
+                                                             DirtyBlocks sel, double2 *__restrict__ part) {
+    const int b = (sel.n > 0) ? sel.blk[blockIdx.y] : (int)blockIdx.y;
+    __shared__ double sx[kWave], sy[kWave], sz[kWave], sq[kWave];
+    if (threadIdx.x < kWave) {
+        const int j = b * kWave + threadIdx.x;
+        const double q = a.q[j];
+        sx[threadIdx.x] = a.x[j];
+        sy[threadIdx.x] = a.y[j];
+        sz[threadIdx.x] = a.z[j];
+        sq[threadIdx.x] = ((a.flags[j] & kValid) && !(a.flags[j] & kFrozen)) ? q : 0.0;
+    }
+    __syncthreads();
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nk) return;
+    const KVec v = kv[k];
+    double re = 0.0, im = 0.0;
+    for (int jj = 0; jj < kWave; ++jj) {
+        const double q = sq[jj];
+        if (q == 0.0) continue;  // wave-uniform
+        double s, c;
+        sincos(v.kx * sx[jj] + v.ky * sy[jj] + v.kz * sz[jj], &s, &c);
+        re += q * c;
+        im += q * s;
+    }
+    part[(size_t)b * nk + k] = make_double2(re, im);
+}
+
+__global__ __launch_bounds__(1024) void recip_sum_kernel(const KVec *__restrict__ kv, int nk, int nblocks,
+                                                          const double2 *__restrict__ part, double *__restrict__ out) {
+    __shared__ double s[16];
+    double acc = 0.0;
+    for (int k = threadIdx.x; k < nk; k += 1024) {
+        double re = 0.0, im = 0.0;
+        for (int b = 0; b < nblocks; ++b) {
+            const double2 p = part[(size_t)b * nk + k];
+            re += p.x;
+            im += p.y;
+        }
+        acc += kv[k].w * (re * re + im * im);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += s[w];
+        out[0] = t;
+    }
+}
+
 // out[c] = sum over rows of in[r][c] (channels <= 4), fixed order: thread t takes rows t, t + 1024, ...,
 // 64-lane butterflies, then the 16 wave sums in order.  One workgroup of kReduceThreads.
 constexpr int kReduceThreads = 1024;
