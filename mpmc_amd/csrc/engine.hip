@@ -183,6 +183,8 @@ struct mpmc_hip_ctx {
     double2 *d_sfpart = nullptr;    // [block][nk] partial structure factors of the reciprocal-space sum
     size_t sfpart_cap = 0;
     bool recip_part_valid = false;
+    bool self_valid = false;        // d_res[R_SELF] holds the Ewald self term of the current charges
+    double self_alpha = 0.0;
     double *d_rankpart = nullptr;   // scratch of the ranking metric (per-tile minima)
     DirtyBlocks dirty_blocks;       // of the energy() call in progress
     bool in_flight = false;         // between energy_begin() and energy_end()
@@ -686,6 +688,7 @@ extern "C" int mpmc_hip_upload(mpmc_hip_ctx *c, int n, const double *x, const do
     c->slot_valid.assign(n, 1);
     c->holes.clear();
     c->lrc_dirty_atoms.clear();
+    c->self_valid = false;
     c->have_atoms = true;
     c->have_polar_result = false;
     c->lrc_valid = false;
@@ -850,6 +853,7 @@ static void mark_edited(mpmc_hip_ctx *c, int first, int count) {
     }
     if ((int)c->dirty_atoms.size() > 4 * kMaxDirty) c->all_dirty = true;
     c->have_polar_result = false;
+    c->self_valid = false;
     ++c->config_rev;
 }
 
@@ -1310,9 +1314,15 @@ static int enqueue_direct(mpmc_hip_ctx *c) {
             } else {
                 HIPCHK(hipMemsetAsync(c->d_res + R_RECIP, 0, sizeof(double), sb));
             }
-            hipLaunchKernelGGL(ewald_self_kernel, dim3(1), dim3(256), 0, sb, a, c->ewald_alpha, c->d_res + R_SELF);
+            // depends on the charges and alpha only: summed at upload / edit / parameter change, then kept in d_res
+            if (!c->self_valid || c->self_alpha != c->ewald_alpha) {
+                hipLaunchKernelGGL(ewald_self_kernel, dim3(1), dim3(256), 0, sb, a, c->ewald_alpha, c->d_res + R_SELF);
+                c->self_valid = true;
+                c->self_alpha = c->ewald_alpha;
+            }
         } else {
             HIPCHK(hipMemsetAsync(c->d_res + R_RECIP, 0, 2 * sizeof(double), sb));
+            c->self_valid = false;
         }
         if (c->opt_overlap) hipEventRecord(c->ev_join, sb);
         return 0;
