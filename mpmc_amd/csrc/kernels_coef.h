@@ -187,7 +187,7 @@ template <int MODE>
 __device__ __forceinline__ void coef_epilogue(const CoefFinish &f, int t, int i, int lane, const double s[3], double al,
                                               int fl, const double old[3], const double es[3], const double aux[3]) {
     const bool valid = fl & kValid;
-    double e_i = 0.0, r_i = 0.0;
+    double e_i = 0.0, r_i = 0.0, emax_i = 0.0;
     if ((MODE == kSweepJacobi && (al == 0.0 || !valid)) || (MODE == kSweepPalmo && !valid)) {
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
@@ -215,9 +215,7 @@ __device__ __forceinline__ void coef_epilogue(const CoefFinish &f, int t, int i,
             f.rrms[i] = rr;
             r_i = rr;
         }
-        // are_we_done_yet (thole_iterative.c:104-113) needs max (new-old)^2: non-negative doubles order like
-        // their bit patterns, so an integer atomicMax is exact and order-independent.
-        atomicMax(f.errmax + f.sp.err_slot, (unsigned long long)__double_as_longlong(emax));
+        emax_i = emax;
         e_i = m[0] * es[0] + m[1] * es[1] + m[2] * es[2];
     } else {
         double m[3], dc[3];
@@ -237,6 +235,14 @@ __device__ __forceinline__ void coef_epilogue(const CoefFinish &f, int t, int i,
     if (lane == 0) {
         f.energy_part[2 * t] = e_i;
         f.energy_part[2 * t + 1] = r_i;
+    }
+    // are_we_done_yet (thole_iterative.c:104-113) needs max (new-old)^2, and only when the stopping rule is a
+    // precision: one atomic per wave after a lane reduction (one per lane, all on one address, cost 3 us of the
+    // 6.5 us this step took).  Non-negative doubles order like their bit patterns, so an integer atomicMax is
+    // exact and order-independent.
+    if (MODE == kSweepJacobi && f.sp.want_err) {
+        emax_i = wave_max(emax_i);
+        if (lane == 0) atomicMax(f.errmax + f.sp.err_slot, (unsigned long long)__double_as_longlong(emax_i));
     }
 }
 

@@ -222,7 +222,9 @@ __global__ __launch_bounds__(256) void gs_finish_kernel(int npad, const double *
         if (!isfinite(rr)) rr = 0.0;
         rrms[i] = (flags[i] & kValid) ? rr : 0.0;
     }
-    if (flags[i] & kValid) atomicMax(errmax + err_slot, (unsigned long long)__double_as_longlong(emax));
+    // one atomic per wave (npad is a multiple of 64, so waves are whole); the value is only read in precision mode
+    emax = wave_max((flags[i] & kValid) ? emax : 0.0);
+    if ((threadIdx.x & 63) == 0) atomicMax(errmax + err_slot, (unsigned long long)__double_as_longlong(emax));
 }
 
 // dst[3k+p] = src[3 perm[k] + p]  (gather into sweep order)   or the inverse scatter

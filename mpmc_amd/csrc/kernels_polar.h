@@ -532,6 +532,7 @@ struct SweepParams {
     double w_new;    // weight of new_mu in mu_out (1 for plain Jacobi)
     double w_old;    // weight of old mu
     int want_rrms;   // polar_rrms || polar_precision > 0
+    int want_err;    // polar_precision > 0: the host reads max (new-old)^2 after every sweep
     int err_slot;    // index into errmax[] for this iteration
 };
 
@@ -619,7 +620,7 @@ __global__ __launch_bounds__(64) void sweep_kernel(const double *__restrict__ A,
             }
             // are_we_done_yet (thole_iterative.c:104-113) needs max (new-old)^2: non-negative doubles
             // order like their bit patterns, so an integer atomicMax is exact and order-independent.
-            atomicMax(errmax + sp.err_slot, (unsigned long long)__double_as_longlong(emax));
+            if (sp.want_err) atomicMax(errmax + sp.err_slot, (unsigned long long)__double_as_longlong(emax));
         } else {
             out[3 * i + 0] = -ef_induced[3 * i + 0] - s0;
             out[3 * i + 1] = -ef_induced[3 * i + 1] - s1;

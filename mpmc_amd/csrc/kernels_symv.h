@@ -202,7 +202,7 @@ __global__ __launch_bounds__(1024) void symv_finish_kernel(int nvpad, const doub
             if (!isfinite(rr)) rr = 0.0;
             rrms[i] = rr;
         }
-        atomicMax(errmax + sp.err_slot, (unsigned long long)__double_as_longlong(emax));
+        if (sp.want_err) atomicMax(errmax + sp.err_slot, (unsigned long long)__double_as_longlong(emax));
     } else {
 #pragma unroll
         for (int p = 0; p < 3; ++p) out[3 * i + p] = -ef_induced[3 * i + p] - s[p];
