@@ -183,6 +183,8 @@ struct mpmc_hip_ctx {
     double2 *d_sfpart = nullptr;    // [block][nk] partial structure factors of the reciprocal-space sum
     size_t sfpart_cap = 0;
     bool recip_part_valid = false;
+    double *d_recipsum = nullptr;   // [ceil(nk/64)] per-chunk sums of w_k |S(k)|^2, folded by the publish kernel
+    int recip_chunks = 0;           // of this call (0: R_RECIP was written directly)
     bool self_valid = false;        // d_res[R_SELF] holds the Ewald self term of the current charges
     double self_alpha = 0.0;
     double *d_rankpart = nullptr;   // scratch of the ranking metric (per-tile minima)
@@ -523,7 +525,7 @@ extern "C" void mpmc_hip_destroy(mpmc_hip_ctx *c) {
     void *dptrs[] = {c->d_x,   c->d_y,     c->d_z,     c->d_q,    c->d_alpha, c->d_eps,      c->d_sig,
                      c->d_molmass, c->d_mol, c->d_flags, c->d_es, c->d_mu,    c->d_efind,    c->d_efchg,
                      c->d_tmp3, c->d_rank, c->d_errmax, c->d_pairpart, c->d_fieldpart, c->d_kvec,
-                     c->d_res,  c->d_kvecf, c->d_sf, c->d_lrcpart, c->d_rankpart, c->d_sfpart};
+                     c->d_res,  c->d_kvecf, c->d_sf, c->d_lrcpart, c->d_rankpart, c->d_sfpart, c->d_recipsum};
     for (void *p : dptrs)
         if (p) hipFree(p);
     for (SweepView &v : c->view) {
@@ -1124,7 +1126,14 @@ static int ensure_static_field(mpmc_hip_ctx *c) {
 // followed by a sequence number the host spins on (no dependence on the device's sync-scheduling mode)
 __global__ void publish_result_kernel(double *__restrict__ d_res, volatile double *__restrict__ h_res, int n,
                                       double seq, const double *__restrict__ energy_part, int nt, int n_total,
-                                      const unsigned *__restrict__ gs_err0, const unsigned *__restrict__ gs_err1) {
+                                      const unsigned *__restrict__ gs_err0, const unsigned *__restrict__ gs_err1,
+                                      const double *__restrict__ recip_chunk, int nrecip) {
+    if (nrecip > 0) {  // reciprocal-space sum: chunk sums in chunk order
+        double e = 0.0;
+        for (int t = threadIdx.x; t < nrecip; t += 64) e += recip_chunk[t];
+        e = mpmc::wave_sum(e);
+        if (threadIdx.x == 0) d_res[R_RECIP] = e;
+    }
     // error words of the persistent Gauss-Seidel launches of this call travel with the result record
     if (threadIdx.x == 0) d_res[R_GS_ERR] = ((gs_err0 && *gs_err0) ? 1.0 : 0.0) + ((gs_err1 && *gs_err1) ? 2.0 : 0.0);
     if (nt > 0) {
@@ -1140,8 +1149,8 @@ __global__ void publish_result_kernel(double *__restrict__ d_res, volatile doubl
             d_res[R_UPOL] = -0.5 * e;
             d_res[R_RRMS] = r / (double)n_total;  // mean over ALL atoms (polar.c:21-27)
         }
-        __syncthreads();
     }
+    __syncthreads();  // thread 0's additions to the record are in place before the record is copied
     if ((int)threadIdx.x < n) h_res[threadIdx.x] = d_res[threadIdx.x];
     __threadfence_system();
     if (threadIdx.x == 0) h_res[n] = seq;
@@ -1179,8 +1188,8 @@ static int launch_recip_partial(mpmc_hip_ctx *c, const DevAtoms &a, hipStream_t 
     DirtyBlocks rsel = c->dirty_blocks;
     if (!c->recip_part_valid || !c->pair_part_valid_before) rsel.n = 0;
     if (c->recip_part_valid && c->pair_part_valid_before && c->dirty_atoms.empty()) return 0;  // nothing moved
-    HIPCHK(launch_slot(c, GS_RECIP, recip_partial_kernel, dim3((c->nk + 255) / 256, rsel.n > 0 ? rsel.n : ntile), dim3(256),
-                       sb, a, (const KVec *)c->d_kvec, c->nk, rsel, c->d_sfpart));
+    HIPCHK(launch_slot(c, GS_RECIP, recip_partial_kernel, dim3((c->nk + 63) / 64, rsel.n > 0 ? rsel.n : ntile),
+                       dim3(64 * kRecipWaves), sb, a, (const KVec *)c->d_kvec, c->nk, rsel, c->d_sfpart));
     c->recip_part_valid = true;
     return 0;
 }
@@ -1190,7 +1199,8 @@ static int launch_publish(mpmc_hip_ctx *c, bool do_polar) {
                        (int)R_COUNT, (double)c->energy_calls, do_polar ? c->energy_part : (const double *)nullptr,
                        do_polar ? c->energy_nt : 0, c->n_valid,
                        c->gs_used[0] ? (const unsigned *)(c->view[0].gsflags + 1) : (const unsigned *)nullptr,
-                       c->gs_used[1] ? (const unsigned *)(c->view[1].gsflags + 1) : (const unsigned *)nullptr));
+                       c->gs_used[1] ? (const unsigned *)(c->view[1].gsflags + 1) : (const unsigned *)nullptr,
+                       (const double *)c->d_recipsum, c->recip_chunks));
     return 0;
 }
 
@@ -1221,6 +1231,7 @@ static void collect_dirty_blocks(mpmc_hip_ctx *c) {
 
 // One evaluation, launch by launch (also what stream capture records for the step graph).
 static int enqueue_direct(mpmc_hip_ctx *c) {
+    c->recip_chunks = 0;
     if (flush_moves(c)) return -1;
     if (is_timed_call(c)) hipEventRecord(c->ev_first, c->stream);
 
@@ -1305,12 +1316,16 @@ static int enqueue_direct(mpmc_hip_ctx *c) {
                     c->d_sfpart = nullptr;
                     c->sfpart_cap = 0;
                     HIPCHK(hipMalloc((void **)&c->d_sfpart, need * sizeof(double2)));
+                    if (c->d_recipsum) hipFree(c->d_recipsum);
+                    c->d_recipsum = nullptr;
+                    HIPCHK(hipMalloc((void **)&c->d_recipsum, ((c->nk + 63) / 64) * sizeof(double)));
                     c->sfpart_cap = need;
                     c->recip_part_valid = false;
                 }
                 if (launch_recip_partial(c, a, sb)) return -1;
-                hipLaunchKernelGGL(recip_sum_kernel, dim3(1), dim3(1024), 0, sb, c->d_kvec, c->nk, ntile, c->d_sfpart,
-                                   c->d_res + R_RECIP);
+                hipLaunchKernelGGL(recip_sum_kernel, dim3((c->nk + 63) / 64), dim3(64 * kRecipGroups), 0, sb, c->d_kvec,
+                                   c->nk, ntile, c->d_sfpart, c->d_recipsum);
+                c->recip_chunks = (c->nk + 63) / 64;
             } else {
                 HIPCHK(hipMemsetAsync(c->d_res + R_RECIP, 0, sizeof(double), sb));
             }

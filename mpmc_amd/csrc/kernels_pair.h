@@ -306,29 +306,34 @@ __global__ __launch_bounds__(256) void ewald_self_kernel(DevAtoms a, double ewal
 // Reciprocal-space Ewald with resident partial structure factors: S_b(k) = sum over the atoms j of the 64-atom
 // block b of q_j e^{i k.r_j} (non-frozen, q != 0; coulombic.c:60-75) is kept per (block, k) between calls, and
 // after a move only the moved atoms' blocks are recomputed -- 64 sincos per k-vector instead of N.
-//   recip_partial_kernel: grid = (ceil(nk / 256), nblocks | sel.n); thread = k-vector, the block's atoms in LDS;
+//   recip_partial_kernel: grid = (ceil(nk / 64), nblocks | sel.n); workgroup = 4 waves, lane = k-vector, each wave
+//                         takes 16 of the block's atoms (from LDS); wave sums combined in wave order;
 //                         part layout [block][nk] (coalesced in k).
-//   recip_sum_kernel:     one workgroup; thread per k adds the block partials in block order, forms
-//                         w_k |S(k)|^2 and the fixed-order total (U_recip up to the 4 pi / V factor).
+//   recip_sum_kernel:     grid = ceil(nk / 64); workgroup = 16 groups x 64 k-vectors: group g adds the block
+//                         partials b = g, g + 16, ... in increasing order, groups are added in order, then
+//                         w_k |S(k)|^2 and the chunk's fixed-order sum -> chunk_sum[chunk] (the publish kernel adds
+//                         the chunks in order: U_recip up to the 4 pi / V factor).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void recip_partial_kernel(DevAtoms a, const KVec *__restrict__ kv, int nk,
-                                                             DirtyBlocks sel, double2 *__restrict__ part) {
+constexpr int kRecipWaves = 4;
+__global__ __launch_bounds__(64 * kRecipWaves) void recip_partial_kernel(DevAtoms a, const KVec *__restrict__ kv, int nk,
+                                                                          DirtyBlocks sel, double2 *__restrict__ part) {
     const int b = (sel.n > 0) ? sel.blk[blockIdx.y] : (int)blockIdx.y;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     __shared__ double sx[kWave], sy[kWave], sz[kWave], sq[kWave];
-    if (threadIdx.x < kWave) {
-        const int j = b * kWave + threadIdx.x;
-        const double q = a.q[j];
-        sx[threadIdx.x] = a.x[j];
-        sy[threadIdx.x] = a.y[j];
-        sz[threadIdx.x] = a.z[j];
-        sq[threadIdx.x] = ((a.flags[j] & kValid) && !(a.flags[j] & kFrozen)) ? q : 0.0;
+    __shared__ double2 red[kRecipWaves][kWave];
+    if (w == 0) {
+        const int j = b * kWave + lane;
+        sx[lane] = a.x[j];
+        sy[lane] = a.y[j];
+        sz[lane] = a.z[j];
+        sq[lane] = ((a.flags[j] & kValid) && !(a.flags[j] & kFrozen)) ? a.q[j] : 0.0;
     }
     __syncthreads();
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= nk) return;
-    const KVec v = kv[k];
+    const int k = blockIdx.x * kWave + lane;
+    const KVec v = kv[min(k, nk - 1)];
     double re = 0.0, im = 0.0;
-    for (int jj = 0; jj < kWave; ++jj) {
+    constexpr int per = kWave / kRecipWaves;
+    for (int jj = w * per; jj < (w + 1) * per; ++jj) {
         const double q = sq[jj];
         if (q == 0.0) continue;  // wave-uniform
         double s, c;
@@ -336,31 +341,47 @@ __global__ __launch_bounds__(256) void recip_partial_kernel(DevAtoms a, const KV
         re += q * c;
         im += q * s;
     }
-    part[(size_t)b * nk + k] = make_double2(re, im);
+    red[w][lane] = make_double2(re, im);
+    __syncthreads();
+    if (w == 0 && k < nk) {
+        double r = 0.0, i = 0.0;
+#pragma unroll
+        for (int u = 0; u < kRecipWaves; ++u) {
+            r += red[u][lane].x;
+            i += red[u][lane].y;
+        }
+        part[(size_t)b * nk + k] = make_double2(r, i);
+    }
 }
 
-__global__ __launch_bounds__(1024) void recip_sum_kernel(const KVec *__restrict__ kv, int nk, int nblocks,
-                                                          const double2 *__restrict__ part, double *__restrict__ out) {
-    __shared__ double s[16];
-    double acc = 0.0;
-    for (int k = threadIdx.x; k < nk; k += 1024) {
-        double re = 0.0, im = 0.0;
-        for (int b = 0; b < nblocks; ++b) {
+constexpr int kRecipGroups = 16;
+__global__ __launch_bounds__(64 * kRecipGroups) void recip_sum_kernel(const KVec *__restrict__ kv, int nk, int nblocks,
+                                                                       const double2 *__restrict__ part,
+                                                                       double *__restrict__ chunk_sum) {
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int k = blockIdx.x * kWave + lane;
+    __shared__ double2 red[kRecipGroups][kWave];
+    double re = 0.0, im = 0.0;
+    if (k < nk) {
+#pragma unroll 4
+        for (int b = g; b < nblocks; b += kRecipGroups) {
             const double2 p = part[(size_t)b * nk + k];
             re += p.x;
             im += p.y;
         }
-        acc += kv[k].w * (re * re + im * im);
     }
-    acc = wave_sum(acc);
-    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+    red[g][lane] = make_double2(re, im);
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = 0.0;
+    if (g != 0) return;
+    double r = 0.0, i = 0.0;
 #pragma unroll
-        for (int w = 0; w < 16; ++w) t += s[w];
-        out[0] = t;
+    for (int u = 0; u < kRecipGroups; ++u) {
+        r += red[u][lane].x;
+        i += red[u][lane].y;
     }
+    double e = (k < nk) ? kv[k].w * (r * r + i * i) : 0.0;
+    e = wave_sum(e);
+    if (lane == 0) chunk_sum[blockIdx.x] = e;
 }
 
 // out[c] = sum over rows of in[r][c] (channels <= 4), fixed order: thread t takes rows t, t + 1024, ...,
