@@ -164,6 +164,31 @@ def test_uvt_incremental_edits_match_full_reuploads():
         h.close()
 
 
+def test_uvt_chain_that_outgrows_its_context():
+    """A box that fills up tenfold under a very high fugacity: thousands of insertions and removals as edits
+    of the resident configuration (reused holes, a growing sweep view, pair / field tile grids that change
+    shape), and along the way the context runs out of slots, so the host re-creates it and uploads again.
+    At the end the energy the chain carries, a fresh evaluation and the oracle must agree, per-atom dipoles
+    included (they come back through the slot map)."""
+    s = synth.s_pol(160, spacing=6.0)
+    p = dict(temperature=77.0, polarization=1, polar_damp=2.1304, polar_max_iter=4, feynman_hibbs=1,
+             feynman_hibbs_order=4)
+    h = host.HostSystem(s, p, seed=5, move_factor=0.05, rot_factor=0.05,
+                        extra={"ensemble": "uvt", "insert_probability": 0.8, "pressure": 50000.0})
+    h.mc_steps(6000)
+    assert h.natoms() > 160 + 80 + 1024, "the context (N + N/2 + 1024 slots) was never outgrown"
+    final = h.system(s["basis"])
+    want = oracle.energy(final, p, want_vectors=True)
+    carried = h.observables()["energy"]
+    fresh = h.energy()
+    # (not bitwise: a re-upload in between re-orders the atoms, and with them the order of the tile sums)
+    assert abs(carried - fresh) <= 1e-12 * abs(fresh)
+    assert abs(fresh - want["energy"]) < 1e-10 * abs(want["energy"])
+    d = h.dipoles()
+    assert np.abs(d["mu"] - want["mu"]).max() <= 1e-10 * np.abs(want["mu"]).max()
+    h.close()
+
+
 def test_driver_executable_on_reference_style_input():
     """mpmc_hip <input> on the 10-atom box: the step-0 line of its energy_output must carry the
     reference's golden numbers (sample_configs_gpu/cuda_pol.small/noncuda_control/small.energy.dat:2)."""
