@@ -164,6 +164,27 @@ def test_uvt_incremental_edits_match_full_reuploads():
         h.close()
 
 
+def test_uvt_chain_without_polarization():
+    """Grand-canonical chain of charged LJ dimers (no polarization): insertions / removals only touch the pair
+    tiles, the reciprocal-space block partials, the long-range-correction tiles and the cached self term."""
+    s = synth.s_es(256)
+    p = dict(synth.FLAGS_ES)
+    h = host.HostSystem(s, p, seed=17, move_factor=0.05, rot_factor=0.05,
+                        extra={"ensemble": "uvt", "insert_probability": 0.7, "pressure": 2000.0})
+    seen = set()
+    for _ in range(20):
+        h.mc_steps(20)
+        seen.add(h.natoms())
+    assert len(seen) > 3
+    final = h.system(s["basis"])
+    want = oracle.energy(final, p)
+    o = h.observables()
+    for key in ("energy", "rd_energy", "coulombic_energy"):
+        assert abs(o[key] - want[key]) < 1e-9 * max(1.0, abs(want[key]), abs(want["rd_energy"])), key
+    assert abs(h.energy() - want["energy"]) < 1e-9 * max(1.0, abs(want["rd_energy"]))
+    h.close()
+
+
 def test_uvt_chain_that_outgrows_its_context():
     """A box that fills up tenfold under a very high fugacity: thousands of insertions and removals as edits
     of the resident configuration (reused holes, a growing sweep view, pair / field tile grids that change
