@@ -12,6 +12,12 @@ reference's sample_configs_gpu/3_PCN61/iter.inp run as NVT (Jacobi x4, cutoff 8 
 Walkers are independent: rank r runs its own chain with seed+r on GPU r; the only
 collective is the sum of a small observable vector every `corrtime` steps (RCCL over xGMI via
 torch.distributed, backend "nccl").  Prints ONE JSON line on rank 0.
+
+A/B switches (none changes what is computed; see include/mpmc_hip.h for the engine options behind them):
+  --expanded-matrix / --full-sweep / --full-rebuild, --uvt, --walkers-per-gpu W, and the environment variables
+  MPMC_OVERLAP=0|1 (second stream), MPMC_SIDE_AFTER=n (where the side stream is fed), MPMC_STEP_GRAPH=1 (HIP-graph
+  replay), MPMC_SYM_MODE, MPMC_GS_DEBUG, MPMC_WALKERS_ONE_THREAD=1, MPMC_HIP_HOST_PROFILE=1 (host-side timing of
+  energy(): printed to stderr when the contexts are destroyed).
 """
 import argparse
 import json
