@@ -43,12 +43,18 @@ void hip_free_shadow(system_t *system) {
     system->hip_shadow = NULL;
 }
 static double g_prof[4]; /* MPMC_HIP_HOST_PROFILE: seconds in walk+diff, begin, bookkeeping, end */
-static long g_prof_calls;
+static long g_prof_calls, g_prof_base;
+static double g_prof_t0, g_prof_tlast;
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 void host_profile_report(void) {
     if (getenv("MPMC_HIP_HOST_PROFILE") && g_prof_calls)
-        fprintf(stderr, "host energy(): %ld calls; walk+diff %.1f us, begin %.1f us, bookkeeping %.1f us, end %.1f us per call\n", g_prof_calls,
-                1e6 * g_prof[0] / g_prof_calls, 1e6 * g_prof[1] / g_prof_calls, 1e6 * g_prof[2] / g_prof_calls, 1e6 * g_prof[3] / g_prof_calls);
+    {
+        const long nc = g_prof_calls - g_prof_base > 0 ? g_prof_calls - g_prof_base : 1;
+        fprintf(stderr, "host energy(): %ld steady-state calls; list walk + updates %.1f us, begin %.1f us, bookkeeping %.1f us, "
+                        "end %.1f us per call; %.1f us per call between energy() calls (MC logic)\n", nc,
+                1e6 * g_prof[0] / nc, 1e6 * g_prof[1] / nc, 1e6 * g_prof[2] / nc, 1e6 * g_prof[3] / nc,
+                1e6 * ((g_prof_tlast - g_prof_t0) - (g_prof[0] + g_prof[1] + g_prof[2] + g_prof[3])) / nc);
+    }
 } /* one engine per process, like the reference's one system per process */
 
 /* reference countNatoms(), energy.c:36-46 */
@@ -171,6 +177,52 @@ static int full_upload(system_t *system) {
     if (rc) return hip_fail("upload");
     system->hip_uploaded_natoms = n;
     system->hip_dirty_all = 0;
+    system->hip_in_sync = 1;
+    system->hip_ntouched = 0;
+    return 0;
+}
+
+void hip_note_touched(system_t *system, molecule_t *m) {
+    if (!system->hip_in_sync) return;
+    for (int k = 0; k < system->hip_ntouched; k++)
+        if (system->hip_touched[k] == m) return;
+    if (system->hip_ntouched == 8) {
+        system->hip_in_sync = 0; /* too many: the next energy() walks the lists */
+        return;
+    }
+    system->hip_touched[system->hip_ntouched++] = m;
+}
+void hip_note_list_changed(system_t *system) { system->hip_in_sync = 0; }
+
+/* one resident molecule against the host image: re-send its coordinates if they differ; returns its atom count */
+static int sync_molecule(system_t *system, shadow_t *sh, molecule_t *m, int *rc) {
+    const int s = m->hip_slot;
+    int k = 0, moved = 0;
+    for (atom_t *a = m->atoms; a; a = a->next, k++)
+        moved |= (a->pos[0] != sh->x[s + k]) | (a->pos[1] != sh->y[s + k]) | (a->pos[2] != sh->z[s + k]);
+    if (!moved) return k;
+    k = 0;
+    for (atom_t *a = m->atoms; a; a = a->next, k++) {
+        sh->x[s + k] = a->pos[0]; sh->y[s + k] = a->pos[1]; sh->z[s + k] = a->pos[2];
+    }
+    if (mpmc_hip_update_atoms(system->hip_ctx, s, k, sh->x + s, sh->y + s, sh->z + s)) *rc = hip_fail("update_atoms");
+    return k;
+}
+
+/* The short way: only the molecules mc.c touched since the device was last in sync (displaced, or put back by
+ * restore()).  Every one must still own its slots -- otherwise the lists changed in a way the notes do not
+ * cover and the caller falls back to the walk.  MPMC_HIP_VERIFY_NOTES=1 cross-checks against the walk. */
+static int sync_touched(system_t *system) {
+    shadow_t *sh = shadow_of(system);
+    int rc = 0;
+    for (int t = 0; t < system->hip_ntouched; t++) {
+        molecule_t *m = system->hip_touched[t];
+        const int s = m->hip_slot;
+        if (m->hip_ticket == 0 || s < 0 || s >= sh->cap || sh->ticket[s] != m->hip_ticket) return 1;
+        sync_molecule(system, sh, m, &rc);
+        if (rc) return rc;
+    }
+    system->hip_ntouched = 0;
     return 0;
 }
 
@@ -201,16 +253,9 @@ static int sync_device(system_t *system) {
             natoms += sh->count[s];
             continue;
         }
-        int k = 0, moved = 0;
-        for (atom_t *a = m->atoms; a; a = a->next, k++)
-            moved |= (a->pos[0] != sh->x[s + k]) | (a->pos[1] != sh->y[s + k]) | (a->pos[2] != sh->z[s + k]);
-        natoms += k;
-        if (!moved) continue;
-        k = 0;
-        for (atom_t *a = m->atoms; a; a = a->next, k++) {
-            sh->x[s + k] = a->pos[0]; sh->y[s + k] = a->pos[1]; sh->z[s + k] = a->pos[2];
-        }
-        if (mpmc_hip_update_atoms(ctx, s, k, sh->x + s, sh->y + s, sh->z + s)) return hip_fail("update_atoms");
+        int rc = 0;
+        natoms += sync_molecule(system, sh, m, &rc);
+        if (rc) return rc;
     }
     /* removals first, so that an insertion of the same size can take the slots */
     for (int f = 0; f < sh->nfirst;) {
@@ -250,6 +295,8 @@ static int sync_device(system_t *system) {
     }
     system->natoms = natoms;
     system->hip_uploaded_natoms = natoms;
+    system->hip_in_sync = 1;
+    system->hip_ntouched = 0;
     return 0;
 }
 
@@ -258,7 +305,30 @@ int energy_begin(system_t *system) {
     const double t0 = now_s();
     int need_upload = !system->hip_ctx || system->hip_dirty_all || system->last_volume != system->pbc->volume;
     if (!need_upload) {
-        const int rc = sync_device(system); /* also counts the atoms (reference countNatoms(), energy.c:36-46) */
+        static int verify = -1;
+        if (verify < 0) verify = getenv("MPMC_HIP_VERIFY_NOTES") != NULL;
+        int rc = 1;
+        if (system->hip_in_sync && !verify) rc = sync_touched(system); /* the noted molecules only */
+        if (rc == 1) {
+            if (verify && system->hip_in_sync) {
+                /* every difference the walk is about to find must be a noted molecule */
+                shadow_t *sh = shadow_of(system);
+                for (molecule_t *m = system->molecules; m; m = m->next) {
+                    const int s = m->hip_slot;
+                    int noted = 0, differs = (m->hip_ticket == 0 || s < 0 || sh->ticket[s] != m->hip_ticket);
+                    for (int t = 0; t < system->hip_ntouched; t++) noted |= (system->hip_touched[t] == m);
+                    int k = 0;
+                    if (!differs)
+                        for (atom_t *a = m->atoms; a; a = a->next, k++)
+                            differs |= (a->pos[0] != sh->x[s + k]) | (a->pos[1] != sh->y[s + k]) | (a->pos[2] != sh->z[s + k]);
+                    if (differs && !noted) {
+                        error("ENERGY: a molecule changed without a note (hip_note_touched)\n");
+                        return -1;
+                    }
+                }
+            }
+            rc = sync_device(system); /* the walk; also counts the atoms (reference countNatoms(), energy.c:36-46) */
+        }
         if (rc < 0) return -1;
         need_upload = rc;
     }
@@ -297,7 +367,12 @@ double energy_end(system_t *system) {
     }
     const double t4 = now_s();
     g_prof[2] += t3 - t2; g_prof[3] += t4 - t3;
-    g_prof_calls++;
+    if (++g_prof_calls == 64) { /* steady state only: forget the upload and the first steps */
+        g_prof[0] = g_prof[1] = g_prof[2] = g_prof[3] = 0.0;
+        g_prof_t0 = t4;
+        g_prof_base = 64;
+    }
+    g_prof_tlast = t4;
     if (system->hip_timing) {
         mpmc_hip_timings t;
         if (!mpmc_hip_get_timings(system->hip_ctx, &t)) {

@@ -453,6 +453,8 @@ void free_system(system_t *system) {
     host_profile_report();
     if (system->hip_ctx) mpmc_hip_destroy(system->hip_ctx);
     hip_free_shadow(system);
+    free(system->movable);
+    free(system->movable_prev);
     molecule_t *m = system->molecules;
     while (m) {
         atom_t *a = m->atoms;

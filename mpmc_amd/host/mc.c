@@ -161,9 +161,29 @@ void checkpoint(system_t *system) {
     checkpoint_t *cp = system->checkpoint;
     memcpy(cp->observables, system->observables, sizeof(observables_t));
 
-    int num_molecules_exchange = 0;
-    for (molecule_t *m = system->molecules; m; m = m->next)
-        if (!m->frozen) ++num_molecules_exchange;
+    /* table of the movable molecules (the reference walks the list for this, twice per step) */
+    if (!system->movable_valid) {
+        int n = 0;
+        for (molecule_t *m = system->molecules; m; m = m->next)
+            if (!m->frozen) ++n;
+        if (n > system->movable_cap) {
+            free(system->movable);
+            free(system->movable_prev);
+            system->movable_cap = 2 * n + 64;
+            system->movable = malloc(system->movable_cap * sizeof(molecule_t *));
+            system->movable_prev = malloc(system->movable_cap * sizeof(molecule_t *));
+        }
+        n = 0;
+        molecule_t *before = NULL;
+        for (molecule_t *m = system->molecules; m; before = m, m = m->next)
+            if (!m->frozen) {
+                system->movable[n] = m;
+                system->movable_prev[n++] = before;
+            }
+        system->nmovable = n;
+        system->movable_valid = 1;
+    }
+    int num_molecules_exchange = system->nmovable;
 
     if (system->ensemble == ENSEMBLE_UVT) {
         if (get_rand(system) < system->insert_probability) {
@@ -179,18 +199,12 @@ void checkpoint(system_t *system) {
     /* randomly pick a (moveable) molecule: floor(rand * N) over the exchangeable ones in list order */
     --num_molecules_exchange;
     int altered = (int)floor(get_rand(system) * system->observables->N);
-    int k = 0;
-    molecule_t *pick = NULL, *prev = NULL, *head = NULL;
-    for (molecule_t *m = system->molecules; m; prev = m, m = m->next) {
-        if (!m->frozen) {
-            if (k == altered) {
-                pick = m;
-                head = prev;
-                break;
-            }
-            k++;
-        }
+    molecule_t *pick = NULL, *head = NULL;
+    if (altered >= 0 && altered < system->nmovable) {
+        pick = system->movable[altered];
+        head = system->movable_prev[altered];
     }
+    cp->altered_index = altered;
     cp->molecule_altered = pick;
     /* never completely empty the list */
     if (!num_molecules_exchange && cp->movetype == MOVETYPE_REMOVE) cp->movetype = MOVETYPE_DISPLACE;
@@ -216,6 +230,8 @@ void make_move(system_t *system) {
                 com[p] = 0;
                 for (int q = 0; q < 3; q++) com[p] += system->pbc->basis[q][p] * rand[q];
             }
+            hip_note_list_changed(system);
+            system->movable_valid = 0;
             molecule_t *ins = cp->molecule_backup;
             ins->hip_ticket = 0; /* a new molecule: it does not own the slots of the one it was copied from */
             ins->hip_slot = -1;
@@ -235,6 +251,8 @@ void make_move(system_t *system) {
             break;
         }
         case MOVETYPE_REMOVE:
+            hip_note_list_changed(system);
+            system->movable_valid = 0;
             /* remove 'altered' from the list */
             if (!cp->head)
                 system->molecules = system->molecules->next;
@@ -246,6 +264,7 @@ void make_move(system_t *system) {
         default:
             translate(system, cp->molecule_altered, system->pbc, system->move_factor);
             rotate(system, cp->molecule_altered, system->pbc, system->rot_factor);
+            hip_note_touched(system, cp->molecule_altered);
     }
 }
 
@@ -255,6 +274,8 @@ void restore(system_t *system) {
     memcpy(system->observables, cp->observables, sizeof(observables_t));
     switch (cp->movetype) {
         case MOVETYPE_INSERT:
+            hip_note_list_changed(system);
+            system->movable_valid = 0;
             /* take altered out of the list */
             if (!cp->head)
                 system->molecules = system->molecules->next;
@@ -264,6 +285,8 @@ void restore(system_t *system) {
             cp->molecule_altered = NULL;
             break;
         case MOVETYPE_REMOVE:
+            hip_note_list_changed(system);
+            system->movable_valid = 0;
             /* put backup back into the list */
             if (!cp->head)
                 system->molecules = cp->molecule_backup;
@@ -280,6 +303,13 @@ void restore(system_t *system) {
                 else
                     cp->head->next = cp->molecule_backup;
                 cp->molecule_backup->next = cp->tail;
+                hip_note_touched(system, cp->molecule_backup); /* the device still holds the rejected coordinates */
+                if (system->movable_valid) { /* the backup takes the altered molecule's place in the table too */
+                    const int k = cp->altered_index;
+                    system->movable[k] = cp->molecule_backup;
+                    if (k + 1 < system->nmovable && system->movable_prev[k + 1] == cp->molecule_altered)
+                        system->movable_prev[k + 1] = cp->molecule_backup;
+                }
                 free_molecule(system, cp->molecule_altered);
                 cp->molecule_altered = NULL;
                 cp->molecule_backup = NULL;

@@ -86,6 +86,7 @@ typedef struct _checkpoint {
     int movetype;
     molecule_t *molecule_altered, *molecule_backup; /* as in the reference: the backup is a deep copy */
     molecule_t *head, *tail;                        /* neighbours of molecule_altered in the list */
+    int altered_index;                              /* its rank among the movable molecules */
     observables_t *observables;
 } checkpoint_t;
 
@@ -123,6 +124,15 @@ typedef struct _system {
     mpmc_hip_ctx *hip_ctx;
     void *hip_shadow; /* host image of the device configuration (energy_hip.c) */
     int hip_device, hip_uploaded_natoms, hip_dirty_all, hip_capacity;
+    /* Which molecules may differ from the device copy since the last energy(): mc.c notes every molecule it
+     * displaces or puts back (hip_note_touched); while hip_in_sync holds, energy() looks at those only instead
+     * of walking all lists.  Anything else that edits the lists clears hip_in_sync (hip_note_list_changed). */
+    int hip_in_sync, hip_ntouched;
+    /* the movable (non-frozen) molecules in list order and each one's predecessor in the list, so that
+     * checkpoint() need not walk the list twice per step; rebuilt after insertions / removals */
+    struct _molecule **movable, **movable_prev;
+    int nmovable, movable_cap, movable_valid;
+    struct _molecule *hip_touched[8];
     mpmc_hip_timings hip_timings_sum; /* accumulated over energy() calls since mc() started */
     int hip_timing;
     FILE *fp_energy;
@@ -142,6 +152,8 @@ void free_system(system_t *system);
 
 /* energy (reference src/energy/energy.c) */
 double energy(system_t *system);
+void hip_note_touched(system_t *system, molecule_t *m);  /* m's atoms moved, or m took a backup's place */
+void hip_note_list_changed(system_t *system);           /* molecules inserted / removed / re-read */
 int energy_begin(system_t *system);  /* energy() in two halves, so that several walkers can share a process */
 double energy_end(system_t *system);
 int countNatoms(system_t *system);
