@@ -1245,10 +1245,7 @@ static int enqueue_direct(mpmc_hip_ctx *c) {
     // (HBM bound) runs on the main stream -- the device-side analogue of the reference starting its
     // polarization worker before the other energy terms (energy.c:108-129, :181-186).
     hipStream_t sb = c->opt_overlap ? c->stream2 : c->stream;
-    if (c->opt_overlap) {
-        hipEventRecord(c->ev_fork, c->stream);
-        hipStreamWaitEvent(sb, c->ev_fork, 0);
-    }
+    if (c->opt_overlap) hipEventRecord(c->ev_fork, c->stream);  // (the side stream's wait is issued when it is fed)
 
     const bool do_polar = !P.rd_only && P.polarization;
     // Enqueue order: the host needs ~3 us per launch and the polarization chain is the critical path, so
@@ -1263,6 +1260,7 @@ static int enqueue_direct(mpmc_hip_ctx *c) {
         if (side_done) return;
         side_done = true;
         side_rc = [&]() -> int {
+        if (c->opt_overlap) hipStreamWaitEvent(sb, c->ev_fork, 0);  // after apply_moves: the new coordinates are in place
         // ---- LJ long-range correction: parameters + volume only => cached (lj.c:56-107)
         if (P.rd_lrc) {
             // depends on parameters, the volume and WHICH atoms exist -- not on coordinates: summed once, its
