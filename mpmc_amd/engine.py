@@ -218,9 +218,40 @@ class Engine:
         cols = [np.ascontiguousarray(pos[:, k]) for k in range(3)]
         _chk(self.lib.mpmc_hip_update_atoms(self.ctx, int(first), pos.shape[0], *[a.ctypes.data for a in cols]))
 
+    def insert_molecule(self, pos, charge, alpha, epsilon, sigma, mass, frozen=False):
+        """One molecule enters the resident configuration (mpmc_hip_insert_molecule).  Returns its first slot, or
+        None when the engine asks for a full upload instead."""
+        pos = np.ascontiguousarray(pos, dtype=np.float64)
+        cols = [np.ascontiguousarray(pos[:, k]) for k in range(3)]
+        arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (charge, alpha, epsilon, sigma, mass)]
+        first = C.c_int(-1)
+        rc = self.lib.mpmc_hip_insert_molecule(self.ctx, pos.shape[0], *[a.ctypes.data for a in cols + arrs],
+                                               int(bool(frozen)), C.byref(first))
+        if rc < 0:
+            _chk(rc)
+        if rc > 0:
+            return None
+        self.n = int(self.lib.mpmc_hip_slot_count(self.ctx))
+        return first.value
+
+    def remove_molecule(self, first, count):
+        """The molecule in slots [first, first + count) leaves (mpmc_hip_remove_molecule); False = upload instead."""
+        rc = self.lib.mpmc_hip_remove_molecule(self.ctx, int(first), int(count))
+        if rc < 0:
+            _chk(rc)
+        return rc == 0
+
     def energy(self):
         r = Result()
         _chk(self.lib.mpmc_hip_energy(self.ctx, C.byref(r)))
+        return {f: getattr(r, f) for f, _ in Result._fields_}
+
+    def energy_begin(self):
+        _chk(self.lib.mpmc_hip_energy_begin(self.ctx))
+
+    def energy_end(self):
+        r = Result()
+        _chk(self.lib.mpmc_hip_energy_end(self.ctx, C.byref(r)))
         return {f: getattr(r, f) for f, _ in Result._fields_}
 
     def dipoles(self):

@@ -398,6 +398,67 @@ def test_ranked_gauss_seidel_chain_keeps_its_view_incrementally():
         e.close()
 
 
+def test_insert_and_remove_molecule_through_the_abi():
+    """mpmc_hip_insert_molecule / remove_molecule on a resident configuration: the edited context must agree
+    with a fresh upload of the same set of atoms (to rounding: the atom order differs), holes are reused, and
+    taking the molecule out again restores the original energies."""
+    s = synth.s_pol(320)
+    p = dict(temperature=77.0, polarization=1, polar_damp=2.1304, polar_max_iter=4, feynman_hibbs=1,
+             feynman_hibbs_order=4)
+    eng = engine.Engine(320 + 64)
+    eng.load_system(s, p)
+    e0 = eng.energy()
+    # a copy of molecule 7, displaced to a gap in the lattice
+    sl = slice(35, 40)
+    newpos = s["pos"][sl] + np.array([1.7, 1.9, -1.6])
+    first = eng.insert_molecule(newpos, s["charge"][sl], s["alpha"][sl], s["epsilon"][sl], s["sigma"][sl], s["mass"][sl])
+    assert first == 320  # appended: no hole yet
+    e1 = eng.energy()
+    assert e1["n_atoms"] == 325
+    s2 = {k: (np.concatenate([v, v[sl]]) if k not in ("basis", "pos", "molecule") else v) for k, v in s.items()}
+    s2["pos"] = np.concatenate([s["pos"], newpos])
+    s2["molecule"] = np.concatenate([s["molecule"], np.full(5, s["molecule"].max() + 1, dtype=np.int32)])
+    want = oracle.energy(s2, p, want_vectors=True)
+    check_energies(e1, want)
+    d = eng.dipoles()
+    assert np.abs(d["mu"][:325] - want["mu"]).max() <= 1e-10 * np.abs(want["mu"]).max()
+    # remove an original molecule: its slots become a hole that the next insertion of that size takes
+    assert eng.remove_molecule(100, 5)
+    e2 = eng.energy()
+    assert e2["n_atoms"] == 320
+    keep = np.r_[0:100, 105:325]
+    s3 = {k: (v[keep] if k != "basis" else v) for k, v in s2.items()}
+    check_energies(e2, oracle.energy(s3, p))
+    back = eng.insert_molecule(s["pos"][100:105], s["charge"][100:105], s["alpha"][100:105], s["epsilon"][100:105],
+                               s["sigma"][100:105], s["mass"][100:105])
+    assert back == 100
+    assert eng.remove_molecule(320, 5)
+    e3 = eng.energy()
+    for key in ("energy", "rd_energy", "coulombic_energy", "polarization_energy"):
+        assert abs(e3[key] - e0[key]) <= 1e-12 * max(1.0, abs(e0[key])), key
+    eng.close()
+
+
+def test_energy_begin_end_protocol():
+    """energy = energy_begin + energy_end; nothing may edit the configuration in between, and the halves must
+    alternate."""
+    s = synth.s_pol(160)
+    p = dict(synth.FLAGS_POL_JACOBI)
+    eng = engine.Engine(160)
+    eng.load_system(s, p)
+    whole = eng.energy()
+    eng.energy_begin()
+    with pytest.raises(engine.EngineError):
+        eng.energy_begin()
+    with pytest.raises(engine.EngineError):
+        eng.update_atoms(0, s["pos"][0:5])
+    halves = eng.energy_end()
+    assert halves["energy"] == whole["energy"] and halves["polarization_energy"] == whole["polarization_energy"]
+    with pytest.raises(engine.EngineError):
+        eng.energy_end()
+    eng.close()
+
+
 def test_step_graph_replay_is_bit_identical_to_direct_launches():
     """Option step_graph: a steady-state MC step is captured once as a HIP graph and replayed with only
     the moved-atom arguments refreshed.  Same kernels, same order of every sum: energies must equal the
