@@ -1440,7 +1440,7 @@ static int graph_step(mpmc_hip_ctx *c) {
     clock_gettime(CLOCK_MONOTONIC, &g0);
     c->graph_mode = GM_UPDATE;
     int rc = flush_moves(c);
-    if (!rc) rc = setup_view(c, c->view[0], a, bx, true, true);
+    if (!rc) rc = setup_view(c, c->view[0], a, bx, true, true, false);
     if (!rc) rc = launch_field(c, a, bx);
     if (!rc) rc = launch_pair_kernel(c, a, bx, c->stream2);
     if (!rc && c->sg.func[GS_RECIP]) rc = launch_recip_partial(c, a, c->stream2);

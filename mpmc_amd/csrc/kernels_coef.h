@@ -399,4 +399,122 @@ __global__ __launch_bounds__(64 * kCoefWaves) void pair_sweep_kernel(const doubl
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Upper-triangle product for the exact Gauss-Seidel sweep (kernels_gs.h): y_k = - sum_{j after k} T_kj mu_old_j.
+// Same tiles, same access pattern as pair_sweep_kernel, but only the row sums are formed (atom k receives from
+// the atoms after it in sweep order) and a diagonal tile keeps the pairs with j > i: 16 B per pair instead of
+// the 72 B per pair gs_upper_kernel reads from the expanded matrix.
+//   pair_upper_kernel:        grid = nt (nt + 1) / 2, block = 256  ->  Srow[tj][192 ti + 64 p + l]
+//   pair_upper_finish_kernel: grid = nvpad / 64, block = 64 x 16: y[3 i + p] = - sum_{tj >= t} Srow, zeros for
+//                             the padding blocks; with `arm` it also prepares the hand-off buffers of the
+//                             persistent lower-triangle kernel (sentinel pattern, flag words zero).
+// ---------------------------------------------------------------------------------------------
+template <int ORTHO>
+__global__ __launch_bounds__(64 * kCoefWaves) void pair_upper_kernel(const double2 *__restrict__ C, int nt, int ntld,
+                                                                       const double *__restrict__ x,
+                                                                       const double *__restrict__ y,
+                                                                       const double *__restrict__ z,
+                                                                       const double *__restrict__ mu, DevBox bx,
+                                                                       double *__restrict__ Srow) {
+    int ti, tj;
+    upper_tile_of(blockIdx.x, nt, ti, tj);
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const bool diag = (ti == tj);
+    __shared__ double2 jxy[64], jzm[64], jmm[64];
+    __shared__ double red[kCoefWaves][3][64];
+    if (w == 0) {
+        const int j = 64 * tj + l;
+        jxy[l] = make_double2(x[j], y[j]);
+        jzm[l] = make_double2(z[j], mu[3 * j]);
+        jmm[l] = make_double2(mu[3 * j + 1], mu[3 * j + 2]);
+    }
+    const int i = 64 * ti + l;
+    const double xi = x[i], yi = y[i], zi = z[i];
+    const double2 *tile = C + (size_t)(ti * ntld + tj) * (kCoefTile * kCoefTile) + (size_t)(kCoefSteps * w) * 64 + l;
+    double2 c[kCoefSteps];
+#pragma unroll
+    for (int k = 0; k < kCoefSteps; ++k) c[k] = stream_load_coef(tile + 64 * k);
+    __syncthreads();
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+#pragma unroll
+    for (int k = 0; k < kCoefSteps; ++k) {
+        const int s = kCoefSteps * w + k;
+        const int jj = (l + s) & 63;
+        const double2 pa = jxy[jj], pb = jzm[jj], pm = jmm[jj];
+        double dx, dy, dz;
+        image_displacement<ORTHO>(bx, xi - pa.x, yi - pa.y, zi - pb.x, dx, dy, dz);
+        // in a diagonal tile only the partners after atom i count (no wrap-around, no self pair)
+        const bool keep = !diag || (s > 0 && l + s < 64);
+        const double c3 = keep ? c[k].x : 0.0, c5m = keep ? -3.0 * c[k].y : 0.0;
+        const double wj = c5m * fma(dz, pm.y, fma(dy, pm.x, dx * pb.y));
+        sx = fma(wj, dx, fma(c3, pb.y, sx));
+        sy = fma(wj, dy, fma(c3, pm.x, sy));
+        sz = fma(wj, dz, fma(c3, pm.y, sz));
+    }
+    red[w][0][l] = sx;
+    red[w][1][l] = sy;
+    red[w][2][l] = sz;
+    __syncthreads();
+    if (w < 3) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < kCoefWaves; ++q) t += red[q][w][l];
+        Srow[(size_t)tj * (3 * (size_t)kCoefTile * nt) + 192 * ti + 64 * w + l] = t;
+    }
+}
+
+__global__ __launch_bounds__(64 * kCoefFinishGroups) void pair_upper_finish_kernel(int nt, const double *__restrict__ Srow,
+                                                                                    double *__restrict__ yout, int arm,
+                                                                                    double *__restrict__ mu_new,
+                                                                                    double *__restrict__ ypart,
+                                                                                    unsigned *__restrict__ gsflags,
+                                                                                    int nflags) {
+    const int t = blockIdx.x;
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int i = 64 * t + lane;
+    if (arm) {  // this block's share of the hand-off buffers (192 doubles each), and the flag words
+        const double sentinel = __longlong_as_double(0x7ff8dead7ff8deadll);
+        if (threadIdx.x < 192) {
+            mu_new[192 * t + threadIdx.x] = sentinel;
+            ypart[192 * t + threadIdx.x] = sentinel;
+        }
+        if (t == 0 && (int)threadIdx.x < nflags) gsflags[threadIdx.x] = 0u;
+    }
+    __shared__ double part[kCoefFinishGroups][3][64];
+    const size_t ncol = 3 * (size_t)kCoefTile * nt;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    if (t < nt) {
+        for (int u0 = g; u0 < nt - t; u0 += 4 * kCoefFinishGroups) {
+            double v[4][3];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int u = u0 + k * kCoefFinishGroups;
+                const bool on = u < nt - t;
+                const double *p = Srow + (size_t)(t + (on ? u : 0)) * ncol + 192 * t + lane;
+                v[k][0] = on ? p[0] : 0.0;
+                v[k][1] = on ? p[64] : 0.0;
+                v[k][2] = on ? p[128] : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                s0 += v[k][0];
+                s1 += v[k][1];
+                s2 += v[k][2];
+            }
+        }
+    }
+    part[g][0][lane] = s0;
+    part[g][1][lane] = s1;
+    part[g][2][lane] = s2;
+    __syncthreads();
+    if (g != 0) return;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < kCoefFinishGroups; ++k) acc += part[k][p][lane];
+        yout[3 * i + p] = -acc;
+    }
+}
+
 }  // namespace mpmc
