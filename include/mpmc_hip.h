@@ -126,8 +126,9 @@ void mpmc_hip_destroy(mpmc_hip_ctx *ctx);
  *   "timing"              (default 1): 0 = record no HIP events; 1 = time the sweep kernels of every 32nd
  *                          call ("timing_interval" changes the 32; plus an empty event pair for calibration); 2 = time every kernel class of every
  *                          call (each event pair costs ~5 microseconds of stream time);
- *   "persistent_gs"       (default 1): Gauss-Seidel lower-triangle phase as one persistent kernel
- *                          (spine + owner workgroups); 0 = two launches per 64-atom block;
+ *   "persistent_gs"       (default 2): Gauss-Seidel lower-triangle phase as one persistent kernel (spine + owner
+ *                          workgroups); 2 = the spine takes the neighbour block from the pair coefficients when the
+ *                          view has >= 20 blocks, 3 = always, 1 = never; 0 = two launches per 64-atom block;
  *   "step_graph"          (default 0): replay a steady-state MC step as a HIP graph (bit-identical; measured
  *                          slower than direct launches on ROCm 7.2). */
 int mpmc_hip_set_option(mpmc_hip_ctx *ctx, const char *name, int value);

@@ -172,7 +172,7 @@ struct mpmc_hip_ctx {
     unsigned long long energy_calls = 0;
     std::vector<int> dirty_atoms;   // atoms moved by update_atoms() since the last energy()
     bool all_dirty = true;
-    int opt_incremental = 1, opt_overlap = 1, opt_symmetric = 1, opt_persistent_gs = 1;
+    int opt_incremental = 1, opt_overlap = 1, opt_symmetric = 1, opt_persistent_gs = 2;
     int opt_pair_coef = 1;  // Jacobi/Palmo sweeps on pair coefficients (0: on the expanded A matrix)
     int opt_incremental_pairs = 1;  // LJ/Ewald-real and static-field tile partials persist between calls
     bool pair_part_valid = false;   // d_pairpart holds the tile partials of the configuration before the pending moves
@@ -426,6 +426,10 @@ extern "C" int mpmc_hip_create(mpmc_hip_ctx **out, int device, int max_atoms) {
     const size_t np = (size_t)c->max_npad;
     c->num_cus = prop.multiProcessorCount;
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(gs_persistent_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, kGsPersistLds));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(gs_persistent2_kernel<0>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, kGsPersistLds));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(gs_persistent2_kernel<1>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, kGsPersistLds));
     /* Two priority classes, so that the two streams never share a hardware queue whatever other streams
      * the process holds (the runtime pools its queues per priority; with RCCL initialised first both

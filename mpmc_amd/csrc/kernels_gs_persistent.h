@@ -22,6 +22,7 @@
 #pragma once
 #include "device_common.h"
 #include "kernels_gs.h"
+#include "kernels_coef.h"  // image_displacement, wave_rotate_down, the coefficient tile layout
 
 namespace mpmc {
 
@@ -34,11 +35,19 @@ struct GsPersist {
     double *ypart;    // [nb][192]
     unsigned *flags;  // [1] error word (zeroed before every launch); mu_new and ypart are pre-filled with kGsSentinel
     int debug;        // reserved
+    // variant 2 (coefficient spine): the pair-coefficient tiles of the same view, its coordinates, the cell
+    const double2 *C;
+    int ntld;
+    const double *px, *py, *pz;
+    DevBox bx;
+    int ortho;
+    int variant;      // 1: owners take every source block s < t; 2: owners take s <= t - 2, the spine the neighbour
 };
 
 constexpr int kGsPairs = kGsBlock * (kGsBlock - 1) / 2;       // 2016
 constexpr int kGsTileDoubles = kGsPairs * 6;                  // 12096
-constexpr int kGsPersistLds = (kGsTileDoubles + 3 * kGsBlock + 8 * 3 * kGsBlock + 8) * 8;  // spine: tile + smu; owner: smu + part[8]
+// spine: tile + smu (+ variant 2: owners' part x2, neighbour partials of 7 waves, coordinates of two blocks); owner: smu + part[8]
+constexpr int kGsPersistLds = (kGsTileDoubles + 3 * kGsBlock + 2 * 3 * kGsBlock + 7 * 3 * kGsBlock + 2 * 3 * kGsBlock + 8) * 8;
 constexpr unsigned kGsSpinLimit = 1u << 24;
 
 __device__ __forceinline__ int gs_row_offset(int j) { return j * (kGsBlock - 1) - j * (j - 1) / 2; }
@@ -100,7 +109,8 @@ __device__ void gs_owner(const GsPersist &p, int first, int stride, double *lds)
         // upper-triangle part of this block's field (previous kernel): fetched now, off the critical path
         const double yu0 = p.y[3 * k], yu1 = p.y[3 * k + 1], yu2 = p.y[3 * k + 2];
         double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-        for (int s = 0; s + 1 <= t; ++s) {
+        const int nsrc = (p.variant == 2) ? t - 1 : t;  // variant 2: the spine adds block t-1's contribution itself
+        for (int s = 0; s < nsrc; ++s) {
             // tile loads first: they do not depend on the dipoles and hide behind the wait
             double tt[8][6];
             const double *base = p.A + (size_t)(3 * (s * kGsBlock + 8 * w)) * p.lda + 3 * (size_t)k;
@@ -269,11 +279,227 @@ __device__ void gs_spine(const GsPersist &p, double *lds) {
 
 // grid = G (2 <= G <= number of CUs, so that every workgroup is resident), block = 512 (8 waves: two
 // per SIMD leaves each thread 256 VGPRs, enough to hold the prefetched tiles without spilling),
+// ---------------------------------------------------------------------------------------------
+// Variant 2 of the spine.  In variant 1 the contribution of the block just solved (t-1) to the next one (t)
+// goes spine -> owner -> spine: two cross-workgroup hand-offs (~3.5 us) on the critical path of every block,
+// because the owner needs the 196 KB neighbour tile of the expanded matrix and one CU cannot fetch that in
+// the ~4 us a chain lasts.  With pair coefficients that tile is 64 KB (and the diagonal one 32 KB instead of
+// 97 KB), so the spine's helper waves prefetch both while the chain of the previous block runs, and
+//   * multiply the neighbour tile with mu_{t-1} themselves (the column product of pair_sweep_kernel: lane =
+//     source atom, the running sums of the target atoms rotate across the lanes), 7 wave partials in LDS;
+//   * expand the diagonal pairs {c3, c5, d} into the tensor entries the chain reads from LDS;
+//   * fetch the owners' part of block t+1 (sources <= t-1, long finished) during the chain of block t.
+// Per block: chain (~4.2 us) + ~1 us, instead of chain + hand-offs (8.8 us).
+// ---------------------------------------------------------------------------------------------
+template <int ORTHO>
+__device__ void gs_spine2(const GsPersist &p, double *lds) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    double *tile = lds;                          // [12096] strictly-upper part of the diagonal tile (tensor entries)
+    double *smu = tile + kGsTileDoubles;         // [192] mu of the block just solved
+    double *ybase = smu + 3 * kGsBlock;          // [2][192] owners' part of the current / next block
+    double *zred = ybase + 2 * 3 * kGsBlock;     // [7][3][64] neighbour partial sums of the helper waves
+    double *pos = zred + 7 * 3 * kGsBlock;       // [2][3][64] coordinates of block t (t & 1) and its predecessor
+    __shared__ int s_ok;
+    const size_t tsz = kCoefTile * kCoefTile;
+
+    // helper thread's share of the diagonal pairs (j, l > j): idx = th + 448 q, row-major over j
+    int dj[5], dl[5];
+    {
+        const int th = (w >= 1 ? (w - 1) * 64 + lane : 0);
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            int jj = 0, rem = th + 448 * q;
+            while (jj < kGsBlock - 1 && rem >= kGsBlock - 1 - jj) {
+                rem -= kGsBlock - 1 - jj;
+                ++jj;
+            }
+            dj[q] = jj;
+            dl[q] = jj + 1 + rem;
+        }
+    }
+    // helper wave w (1..7) takes the steps [sb, se) of the neighbour tile: 9 or 10 of the 64
+    const int sb = (w >= 1) ? ((w - 1) * kGsBlock) / 7 : 0, se = (w >= 1) ? (w * kGsBlock) / 7 : 0;
+    constexpr int kNbSteps = 10;
+    double2 cn[kNbSteps];  // neighbour coefficients of the NEXT block boundary
+    double2 cd[5];         // diagonal pairs of the NEXT block
+    auto prefetch = [&](int tn) {  // everything block tn needs from HBM
+        if (w == 0) return;
+        const int th = (w - 1) * 64 + lane;
+        const double2 *dt = p.C + (size_t)(tn * p.ntld + tn) * tsz;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const int idx = th + 448 * q;
+            cd[q] = (idx < kGsPairs) ? dt[(dl[q] - dj[q]) * 64 + dj[q]] : make_double2(0.0, 0.0);
+        }
+        if (tn >= 1) {
+            const double2 *nt_ = p.C + (size_t)((tn - 1) * p.ntld + tn) * tsz + lane;
+#pragma unroll
+            for (int k = 0; k < kNbSteps; ++k) cn[k] = (sb + k < se) ? nt_[(sb + k) * 64] : make_double2(0.0, 0.0);
+        }
+        if (th < 3 * kGsBlock) {  // coordinates of block tn, [component][atom]
+            const int comp = th / kGsBlock, a = th % kGsBlock;
+            const double *src = comp == 0 ? p.px : (comp == 1 ? p.py : p.pz);
+            pos[(tn & 1) * 3 * kGsBlock + comp * kGsBlock + a] = src[tn * kGsBlock + a];
+        }
+    };
+    auto fetch_ybase = [&](int tn, bool &ok) {  // owners' part of block tn -> LDS (data-is-the-flag poll)
+        if (w >= 1) {
+            const int th = (w - 1) * 64 + lane;
+            if (th < 3 * kGsBlock)
+                ybase[(tn & 1) * 3 * kGsBlock + th] = poll_value(p.ypart + (size_t)tn * 3 * kGsBlock + th, p.flags + 1, ok);
+        }
+    };
+
+    if (tid == 0) s_ok = 1;
+    __syncthreads();
+    prefetch(0);
+    {
+        bool ok = true;
+        fetch_ybase(0, ok);
+        if (!ok) s_ok = 0;
+    }
+    __syncthreads();
+    for (int t = 0; t < p.nb; ++t) {
+        if (!s_ok) return;
+        const double *pc = pos + (t & 1) * 3 * kGsBlock, *pp = pos + ((t - 1) & 1) * 3 * kGsBlock;
+        // ---- helpers: [A] neighbour tile x mu_{t-1}, [B] diagonal pairs -> tensor entries in LDS
+        if (w >= 1) {
+            if (t >= 1) {
+                const double xi = pp[lane], yi = pp[kGsBlock + lane], zi = pp[2 * kGsBlock + lane];
+                const double mix = smu[3 * lane], miy = smu[3 * lane + 1], miz = smu[3 * lane + 2];
+                double zx = 0.0, zy = 0.0, zz = 0.0;
+#pragma unroll
+                for (int k = 0; k < kNbSteps; ++k) {
+                    const int s = sb + k;
+                    if (k > 0 && s < se) {  // (wave-uniform) the sums follow their target atom to the next lane
+                        zx = wave_rotate_down(zx);
+                        zy = wave_rotate_down(zy);
+                        zz = wave_rotate_down(zz);
+                    }
+                    if (s < se) {
+                        const int jj = (lane + s) & 63;
+                        double dx, dy, dz;
+                        image_displacement<ORTHO>(p.bx, xi - pc[jj], yi - pc[kGsBlock + jj], zi - pc[2 * kGsBlock + jj], dx,
+                                                  dy, dz);
+                        const double c3 = cn[k].x, c5m = -3.0 * cn[k].y;
+                        const double wi = c5m * fma(dz, miz, fma(dy, miy, dx * mix));
+                        zx = fma(wi, dx, fma(c3, mix, zx));
+                        zy = fma(wi, dy, fma(c3, miy, zy));
+                        zz = fma(wi, dz, fma(c3, miz, zz));
+                    }
+                }
+                const int jl = (lane + se - 1) & 63;  // target atom this lane ended on
+                zred[((w - 1) * 3 + 0) * kGsBlock + jl] = zx;
+                zred[((w - 1) * 3 + 1) * kGsBlock + jl] = zy;
+                zred[((w - 1) * 3 + 2) * kGsBlock + jl] = zz;
+            }
+            const int th = (w - 1) * 64 + lane;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                const int idx = th + 448 * q;
+                if (idx < kGsPairs) {
+                    const int j = dj[q], l = dl[q];
+                    double dx, dy, dz;
+                    image_displacement<ORTHO>(p.bx, pc[j] - pc[l], pc[kGsBlock + j] - pc[kGsBlock + l],
+                                              pc[2 * kGsBlock + j] - pc[2 * kGsBlock + l], dx, dy, dz);
+                    const double c3 = cd[q].x, c5 = cd[q].y;
+                    const int wd = kGsBlock - 1 - j;
+                    double *dst = tile + (size_t)gs_row_offset(j) * 6 + (l - j - 1);
+                    dst[0 * wd] = -3.0 * dx * dx * c5 + c3;  // xx, xy, xz, yy, yz, zz as thole_tensor()
+                    dst[1 * wd] = -3.0 * dx * dy * c5;
+                    dst[2 * wd] = -3.0 * dx * dz * c5;
+                    dst[3 * wd] = -3.0 * dy * dy * c5 + c3;
+                    dst[4 * wd] = -3.0 * dy * dz * c5;
+                    dst[5 * wd] = -3.0 * dz * dz * c5 + c3;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- helpers: everything block t+1 needs, while wave 0 runs the chain of block t
+        bool okh = true;
+        if (w != 0 && t + 1 < p.nb) {
+            prefetch(t + 1);
+            fetch_ybase(t + 1, okh);
+        }
+
+        if (w == 0) {
+            const int k = t * kGsBlock + lane;
+            const double al = p.alpha[k];
+            const double ae0 = al * p.es[3 * k], ae1 = al * p.es[3 * k + 1], ae2 = al * p.es[3 * k + 2];
+            const double *yb = ybase + (t & 1) * 3 * kGsBlock;
+            double y0 = yb[3 * lane], y1 = yb[3 * lane + 1], y2 = yb[3 * lane + 2];
+            if (t >= 1) {  // minus the neighbour block's contribution, wave partials in wave order
+#pragma unroll
+                for (int g = 0; g < 7; ++g) {
+                    y0 -= zred[(g * 3 + 0) * kGsBlock + lane];
+                    y1 -= zred[(g * 3 + 1) * kGsBlock + lane];
+                    y2 -= zred[(g * 3 + 2) * kGsBlock + lane];
+                }
+            }
+            double c[6];
+            {
+                const double *tp = tile + (lane - 1);
+#pragma unroll
+                for (int e = 0; e < 6; ++e) c[e] = tp[e * (kGsBlock - 1)];
+            }
+#pragma unroll
+            for (int j = 0; j < kGsBlock - 1; ++j) {
+                double n[6] = {0, 0, 0, 0, 0, 0};
+                if (j + 1 < kGsBlock - 1) {
+                    const int wd = kGsBlock - 2 - j;
+                    const double *tp = tile + gs_row_offset(j + 1) * 6 + (lane - j - 2);
+#pragma unroll
+                    for (int e = 0; e < 6; ++e) n[e] = tp[e * wd];
+                }
+                const double bx = readlane_f64(fma(al, y0, ae0), j);
+                const double by = readlane_f64(fma(al, y1, ae1), j);
+                const double bz = readlane_f64(fma(al, y2, ae2), j);
+                if (lane > j) {
+                    y0 = fma(-c[0], bx, y0);
+                    y0 = fma(-c[1], by, y0);
+                    y0 = fma(-c[2], bz, y0);
+                    y1 = fma(-c[1], bx, y1);
+                    y1 = fma(-c[3], by, y1);
+                    y1 = fma(-c[4], bz, y1);
+                    y2 = fma(-c[2], bx, y2);
+                    y2 = fma(-c[4], by, y2);
+                    y2 = fma(-c[5], bz, y2);
+                }
+#pragma unroll
+                for (int e = 0; e < 6; ++e) c[e] = n[e];
+            }
+            const double m0 = fma(al, y0, ae0), m1 = fma(al, y1, ae1), m2 = fma(al, y2, ae2);
+            smu[3 * lane] = m0;
+            smu[3 * lane + 1] = m1;
+            smu[3 * lane + 2] = m2;
+            st_agent(p.mu_new + 3 * k, m0);
+            st_agent(p.mu_new + 3 * k + 1, m1);
+            st_agent(p.mu_new + 3 * k + 2, m2);
+            p.y[3 * k] = y0;  // E_induced of the atom when it was updated (thole_iterative.c:44-46)
+            p.y[3 * k + 1] = y1;
+            p.y[3 * k + 2] = y2;
+        }
+        if (!okh) s_ok = 0;
+        __syncthreads();
+    }
+}
+
 // dynamic LDS = kGsPersistLds
 __global__ __launch_bounds__(512) void gs_persistent_kernel(GsPersist p) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     if (blockIdx.x == 0)
         gs_spine(p, lds);
+    else
+        gs_owner(p, (int)blockIdx.x - 1, (int)gridDim.x - 1, lds);
+}
+
+// variant 2: coefficient spine (a kernel of its own: the two spines together do not fit the register file)
+template <int ORTHO>
+__global__ __launch_bounds__(512) void gs_persistent2_kernel(GsPersist p) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    if (blockIdx.x == 0)
+        gs_spine2<ORTHO>(p, lds);
     else
         gs_owner(p, (int)blockIdx.x - 1, (int)gridDim.x - 1, lds);
 }

@@ -360,7 +360,8 @@ def test_incremental_updates_are_bit_identical_to_full_recomputation(pair_coeffi
         e.close()
 
 
-def test_ranked_gauss_seidel_chain_keeps_its_view_incrementally():
+@pytest.mark.parametrize("persistent_gs", [2, 3, 1])
+def test_ranked_gauss_seidel_chain_keeps_its_view_incrementally(persistent_gs):
     """Production flags (Wolf field, ranked Gauss-Seidel, Palmo, gamma 1.03): the ranked view's matrix stays
     resident while the ranked walk does not change and only the moved atoms' rows / columns are rewritten;
     the static-field and pair partials persist too.  A chain of moves must give bitwise the energies of an
@@ -374,6 +375,7 @@ def test_ranked_gauss_seidel_chain_keeps_its_view_incrementally():
         e.load_system(s, p)
         e.set_option("incremental_amatrix", inc)
         e.set_option("incremental_pairs", inc)
+        e.set_option("persistent_gs", persistent_gs)  # 3: coefficient spine also for this small view, 1: never
         engs.append(e)
     pos = s["pos"].copy()
     for step in range(10):
