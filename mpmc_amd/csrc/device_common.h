@@ -43,6 +43,7 @@ struct DevBox {
     float fb[3][3];   // single-precision copies for the cutoff pre-filter
     float frb[3][3];
     float rc2_pre;    // (cutoff + 0.01 A)^2
+    int screen64;     // some |coordinate| is too large for the fp32 screen: screen on fp64 displacements (see below)
 };
 
 // SoA view of the configuration resident in HBM.  All arrays have npad entries
@@ -160,9 +161,25 @@ __device__ __forceinline__ void minimum_image_sq(const DevBox &bx, double dx, do
 // rounding of coordinates below ~100 A moves a distance by < 1e-4 A, and if fp32 picks the other image
 // of a tie both images are equidistant to that accuracy, so no pair the exact test accepts is lost.
 // Pairs that pass are decided by the exact fp64 path as before, so results are unchanged.
+//
+// Guard: the reference never wraps atom->pos (wrapall() only fills wrapped_pos, src/io/output.c:142-183) and a
+// PQR may sit anywhere, so coordinates are not bounded by the box.  An fp32 coordinate carries an error of
+// |x| 2^-24; with |x| <= kScreen32MaxCoord = 2048 A the screened distance is off by < 2e-3 A, well inside the
+// 0.01 A margin.  The host tracks max |coordinate| over everything it sends (upload / update_atoms /
+// insert_molecule) and above that bound sets DevBox::screen64: the screen then works on fp64 displacements,
+// lattice reduction included (contracted arithmetic; exact to ~1e-10 A up to |x| ~ 1e5 A and never worse than
+// the exact path's own resolution), so no in-cutoff pair can be dropped however far the atoms sit.
+constexpr double kScreen32MaxCoord = 2048.0;
 __device__ __forceinline__ bool prefilter_within_f(const DevBox &bx, float dx, float dy, float dz);
-__device__ __forceinline__ bool prefilter_within(const DevBox &bx, double dxd, double dyd, double dzd) {
-    return prefilter_within_f(bx, (float)dxd, (float)dyd, (float)dzd);
+__device__ __forceinline__ bool prefilter_within_d(const DevBox &bx, double dx, double dy, double dz) {
+    const double i0 = rint(bx.rb[0][0] * dx + bx.rb[1][0] * dy + bx.rb[2][0] * dz);
+    const double i1 = rint(bx.rb[0][1] * dx + bx.rb[1][1] * dy + bx.rb[2][1] * dz);
+    const double i2 = rint(bx.rb[0][2] * dx + bx.rb[1][2] * dy + bx.rb[2][2] * dz);
+    const double ex = dx - (bx.b[0][0] * i0 + bx.b[1][0] * i1 + bx.b[2][0] * i2);
+    const double ey = dy - (bx.b[0][1] * i0 + bx.b[1][1] * i1 + bx.b[2][1] * i2);
+    const double ez = dz - (bx.b[0][2] * i0 + bx.b[1][2] * i1 + bx.b[2][2] * i2);
+    const double r2 = ex * ex + ey * ey + ez * ez;
+    return !(r2 > (double)bx.rc2_pre);  // NaN passes: the exact path handles it
 }
 // same screen on single-precision displacements (coordinates rounded to fp32 when a tile is staged:
 // |x| < 64 A => 4e-6 A per coordinate, far inside the 0.01 A margin)

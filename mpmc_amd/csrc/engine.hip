@@ -211,6 +211,7 @@ struct mpmc_hip_ctx {
     int call_iterations = 0, call_iter_success = 0;
     std::function<void()> enqueue_side;  // set while run_polarization() may feed the side stream (see energy())
     double host_enqueue_s = 0.0, host_wait_s = 0.0;  // MPMC_HIP_HOST_PROFILE=1: printed at destroy
+    double coord_max = 0.0; // max |coordinate| of everything sent since the last upload (guards the fp32 screen)
     bool box_ortho = false; // every off-diagonal basis entry is exactly zero
     int num_cus = 256;
     int opt_timing = 1;    // 0: no events, 1: sweep kernels + total only, 2: every kernel class
@@ -290,10 +291,24 @@ static DevBox dev_box(const mpmc_hip_ctx *c) {
             b.frb[p][q] = (float)c->recip[p][q];
         }
     b.rc2_pre = (float)((c->cutoff + 0.01) * (c->cutoff + 0.01));
+    b.screen64 = (c->coord_max > kScreen32MaxCoord || !(c->coord_max == c->coord_max)) ? 1 : 0;
     return b;
 }
 
 static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// running maximum of |coordinate| (device_common.h: above kScreen32MaxCoord the pair / field screens switch
+// from fp32 to fp64 displacements); a NaN coordinate switches too
+static void note_coords(mpmc_hip_ctx *c, const double *x, const double *y, const double *z, int count) {
+    double m = c->coord_max;
+    for (int i = 0; i < count; ++i) {
+        const double v = std::max(std::fabs(x[i]), std::max(std::fabs(y[i]), std::fabs(z[i])));
+        if (!(v <= m)) m = (v == v) ? v : INFINITY;
+    }
+    const bool was64 = c->coord_max > kScreen32MaxCoord;
+    c->coord_max = m;
+    if ((m > kScreen32MaxCoord) != was64) ++c->config_rev;  // a captured step graph carries the old DevBox
+}
 
 // timing 1: events around the sweep kernels of every 32nd call (an event pair costs ~5 us of stream time and
 // reading the events back stalls the host: sampling every 8th call cost 10 % of the step rate); 2: every call;
@@ -687,6 +702,8 @@ extern "C" int mpmc_hip_upload(mpmc_hip_ctx *c, int n, const double *x, const do
     HIPCHK(hipMemcpyAsync(c->d_mol, hmol.data(), bi, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->d_flags, hfl.data(), bi, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    c->coord_max = 0.0;
+    note_coords(c, x, y, z, n);
     c->n = n;
     c->npad = npad;
     c->n_valid = n;
@@ -747,6 +764,7 @@ extern "C" int mpmc_hip_update_atoms(mpmc_hip_ctx *c, int first, int count, cons
         return fail("MPMC_HIP: update_atoms: range [%d, %d) outside [0, %d)", first, first + count, c->n);
     if (!x || !y || !z) return fail("MPMC_HIP: update_atoms: null array");
     HIPCHK(hipSetDevice(c->device));
+    note_coords(c, x, y, z, count);
     const size_t b = count * sizeof(double);
     bool queued = false;
     if (count <= kMaxMoves) {
@@ -901,6 +919,7 @@ extern "C" int mpmc_hip_insert_molecule(mpmc_hip_ctx *c, int count, const double
         return fail("MPMC_HIP: insert_molecule: bad arguments");
     if (count > kMaxEdit || !edits_supported(c)) return 1;
     HIPCHK(hipSetDevice(c->device));
+    note_coords(c, x, y, z, count);
     SweepView &v0 = c->view[0];
     // a hole of exactly this size (most recent first), else new slots at the end
     int first = -1, hole = -1;

@@ -3,10 +3,14 @@
 //
 // Replaces the linked pair-list walk of the reference (src/energy/pairs.c:293-361,
 // lj.c:165-276, coulombic.c:149-194): no pair list is stored; geometry is recomputed
-// on the fly from SoA coordinates.  One wave owns a 64-atom i-tile (lane = atom i), the
-// 64-atom j-tile is staged in LDS and broadcast to all lanes; energy partials are reduced
-// with 64-lane shuffles and summed in a fixed order by a finalisation kernel, so results
-// are bitwise reproducible run to run.
+// on the fly from SoA coordinates.  A workgroup of 8 waves owns one 64 x 64-atom tile: in
+// every wave lane = row atom i, and the wave takes 8 of the 64 column atoms, which are staged
+// in LDS and broadcast to all lanes.  Two phases per tile: a cheap fp32 screen (flags + minimum
+// image at cutoff + margin; fp64 differences when the coordinates are too large for fp32, see
+// DevBox::screen64) sets one candidate bit per partner, then the exact fp64 path runs over the
+// set bits only.  Tile partials persist between calls (only the tiles of moved atoms' blocks are
+// redone); they are reduced with 64-lane shuffles and summed in a fixed order by a finalisation
+// kernel, so results are bitwise reproducible run to run and independent of the update history.
 #pragma once
 #include "device_common.h"
 
@@ -97,7 +101,10 @@ __global__ __launch_bounds__(64 * kPairWaves) void pair_rd_es_kernel(DevAtoms a,
         const int flj = t.flags[jj];
         // pair (i<j), both real atoms, not frozen-frozen (lj.c:193, coulombic.c:165)
         const bool act = (j > i) && (fli & kValid) && (flj & kValid) && !((fli & kFrozen) && (flj & kFrozen));
-        if (act && ((moli == t.mol[jj]) || prefilter_within_f(bx, xif - t.fx[jj], yif - t.fy[jj], zif - t.fz[jj])))
+        // (bx.screen64 is wave-uniform: a kernel argument)
+        if (act && ((moli == t.mol[jj]) ||
+                    (bx.screen64 ? prefilter_within_d(bx, xi - t.x[jj], yi - t.y[jj], zi - t.z[jj])
+                                 : prefilter_within_f(bx, xif - t.fx[jj], yif - t.fy[jj], zif - t.fz[jj]))))
             cand |= (1ull << jj);
     }
     while (cand) {

@@ -96,7 +96,9 @@ __global__ __launch_bounds__(64 * kFieldWaves) void static_field_kernel(DevAtoms
             // bare / Wolf fields skip same-molecule pairs (thole_field.c:50,96); the Ewald real term keeps
             // them and gives them the screening form instead (polar_ewald.c:52-60)
             if (MODE != kFieldEwald) act = act && (moli != smol[jj]);
-            if (act && prefilter_within_f(bx, xif - fx[jj], yif - fy[jj], zif - fz[jj])) cand |= (1ull << jj);
+            if (act && (bx.screen64 ? prefilter_within_d(bx, xi - sx[jj], yi - sy[jj], zi - sz[jj])
+                                    : prefilter_within_f(bx, xif - fx[jj], yif - fy[jj], zif - fz[jj])))
+                cand |= (1ull << jj);
         }
         while (cand) {
             const int jj = __ffsll((long long)cand) - 1;

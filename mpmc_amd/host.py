@@ -8,7 +8,8 @@ import numpy as np
 from . import engine
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "host", "libmpmc_host.so")
+# MPMC_HOST_LIB: the sanitizer build (make -C mpmc_amd/host asan) for tests/run_asan.sh
+LIB_PATH = os.environ.get("MPMC_HOST_LIB") or os.path.join(_HERE, "host", "libmpmc_host.so")
 EXE_PATH = os.path.join(_HERE, "host", "mpmc_hip")
 
 _lib = None

@@ -38,7 +38,7 @@ int host_mc_steps(system_t *system, int nsteps) {
         /* first call: initial energy + first checkpoint, as mc() does */
         system->observables->volume = system->pbc->volume;
         double e = energy(system);
-        if (e != e) return -1;
+        if (system->hip_error || e != e) return -1;
         checkpoint(system);
         system->avg_observables->counter = 1.0;
     }
@@ -47,6 +47,7 @@ int host_mc_steps(system_t *system, int nsteps) {
         const double initial_energy = system->observables->energy;
         make_move(system);
         const double final_energy = energy(system);
+        if (system->hip_error) return -1; /* device failure: stop, never count it as a reject */
         if (final_energy != final_energy || final_energy - final_energy != 0.0) {
             system->observables->energy = MAXVALUE;
             system->nodestats->boltzmann_factor = 0;
@@ -75,7 +76,7 @@ int host_mc_steps_multi(system_t **systems, int nwalkers, int nsteps) {
         if (system->step == 0 && system->avg_observables->counter == 0.0) {
             system->observables->volume = system->pbc->volume;
             double e = energy(system);
-            if (e != e) return -1;
+            if (system->hip_error || e != e) return -1;
             checkpoint(system);
             system->avg_observables->counter = 1.0;
         }
@@ -91,9 +92,14 @@ int host_mc_steps_multi(system_t **systems, int nwalkers, int nsteps) {
             make_move(system);
             ok[w] = (energy_begin(system) == 0);
         }
+        int failed = 0;
+        for (int w = 0; w < nwalkers; w++) failed |= !ok[w];
         for (int w = 0; w < nwalkers; w++) {
             system_t *system = systems[w];
+            /* every evaluation in flight is collected, also after a failure, so that no context is left mid-call */
             const double final_energy = ok[w] ? energy_end(system) : NAN;
+            failed |= system->hip_error;
+            if (failed) continue;
             if (final_energy != final_energy || final_energy - final_energy != 0.0) {
                 system->observables->energy = MAXVALUE;
                 system->nodestats->boltzmann_factor = 0;
@@ -109,6 +115,7 @@ int host_mc_steps_multi(system_t **systems, int nwalkers, int nsteps) {
                 ++system->nodestats->reject;
             }
         }
+        if (failed) return -1;
     }
     return accepted;
 }
@@ -171,6 +178,7 @@ int host_set_option(system_t *system, const char *name, int value) {
 }
 
 int host_natoms(system_t *system) { return countNatoms(system); }
+int host_device_error(system_t *system) { return system->hip_error; }
 /* full flat copy of the current configuration (N may have changed under uvt) */
 void host_get_system(system_t *system, double *pos, double *charge, double *alpha, double *eps, double *sig,
                      double *mass, int *molecule, int *frozen) {

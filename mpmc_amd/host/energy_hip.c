@@ -123,6 +123,16 @@ static int hip_fail(const char *what) {
     return -1;
 }
 
+/* every error return of energy_begin() / energy_end() goes through here: the failure is recorded in its own
+ * channel (system->hip_error) and the notes about touched molecules are dropped -- restore() may free a
+ * molecule that is still listed there -- so the next energy(), if the caller tries one, walks the lists */
+static int device_failed(system_t *system) {
+    system->hip_error = 1;
+    system->hip_ntouched = 0;
+    system->hip_in_sync = 0;
+    return -1;
+}
+
 static int shadow_reserve(shadow_t *sh, int cap) {
     if (sh->cap >= cap) return 0;
     free(sh->x); free(sh->y); free(sh->z); free(sh->ticket); free(sh->count); free(sh->seen); free(sh->first);
@@ -220,7 +230,11 @@ static int sync_touched(system_t *system) {
         const int s = m->hip_slot;
         if (m->hip_ticket == 0 || s < 0 || s >= sh->cap || sh->ticket[s] != m->hip_ticket) return 1;
         sync_molecule(system, sh, m, &rc);
-        if (rc) return rc;
+        if (rc) {
+            system->hip_ntouched = 0; /* never keep a note across an error: the molecule may be freed by restore() */
+            system->hip_in_sync = 0;
+            return rc;
+        }
     }
     system->hip_ntouched = 0;
     return 0;
@@ -303,6 +317,7 @@ static int sync_device(system_t *system) {
 /* First half of energy(): bring the device in line with the lists and enqueue the evaluation. */
 int energy_begin(system_t *system) {
     const double t0 = now_s();
+    system->hip_error = 0;
     int need_upload = !system->hip_ctx || system->hip_dirty_all || system->last_volume != system->pbc->volume;
     if (!need_upload) {
         static int verify = -1;
@@ -323,13 +338,13 @@ int energy_begin(system_t *system) {
                             differs |= (a->pos[0] != sh->x[s + k]) | (a->pos[1] != sh->y[s + k]) | (a->pos[2] != sh->z[s + k]);
                     if (differs && !noted) {
                         error("ENERGY: a molecule changed without a note (hip_note_touched)\n");
-                        return -1;
+                        return device_failed(system);
                     }
                 }
             }
             rc = sync_device(system); /* the walk; also counts the atoms (reference countNatoms(), energy.c:36-46) */
         }
-        if (rc < 0) return -1;
+        if (rc < 0) return device_failed(system);
         need_upload = rc;
     }
     if (need_upload) {
@@ -341,13 +356,19 @@ int energy_begin(system_t *system) {
         if (!system->hip_ctx) {
             /* head-room for insertions: a context is sized once, like the reference's pair-list growth steps */
             system->hip_capacity = system->natoms + (system->ensemble == ENSEMBLE_UVT ? system->natoms / 2 + 1024 : 0);
-            if (mpmc_hip_create(&system->hip_ctx, system->hip_device, system->hip_capacity)) return hip_fail("create");
+            if (mpmc_hip_create(&system->hip_ctx, system->hip_device, system->hip_capacity)) {
+                hip_fail("create");
+                return device_failed(system);
+            }
         }
         if (system->last_volume != system->pbc->volume) pbc(system);
-        if (full_upload(system)) return -1;
+        if (full_upload(system)) return device_failed(system);
     }
     const double t1 = now_s();
-    if (mpmc_hip_energy_begin(system->hip_ctx)) return hip_fail("energy");
+    if (mpmc_hip_energy_begin(system->hip_ctx)) {
+        hip_fail("energy");
+        return device_failed(system);
+    }
     g_prof[0] += t1 - t0;
     g_prof[1] += now_s() - t1;
     return 0;
@@ -363,6 +384,7 @@ double energy_end(system_t *system) {
     mpmc_hip_result r;
     if (mpmc_hip_energy_end(system->hip_ctx, &r)) {
         hip_fail("energy");
+        device_failed(system);
         return NAN;
     }
     const double t4 = now_s();
@@ -398,8 +420,10 @@ double energy_end(system_t *system) {
     return o->energy;
 }
 
+/* A non-finite return with system->hip_error == 0 is a bad contact, which mc.c treats as a reject
+ * (reference mc.c:315-318); with hip_error set it is a device / ABI failure and the chain must stop. */
 double energy(system_t *system) {
-    if (energy_begin(system)) return NAN; /* mc.c treats a non-finite energy as a reject (mc.c:315-318) */
+    if (energy_begin(system)) return NAN;
     return energy_end(system);
 }
 

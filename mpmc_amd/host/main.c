@@ -23,6 +23,7 @@ int main(int argc, char **argv) {
     int rc = 0;
     if (system->ensemble == ENSEMBLE_TE) {
         const double e = energy(system);
+        if (system->hip_error) rc = -1;
         const observables_t *o = system->observables;
         snprintf(linebuf, MAXLINE,
                  "OUTPUT: potential energy = %.5f K\nOUTPUT: electrostatic energy = %.5f K\n"

@@ -365,6 +365,7 @@ int mc(system_t *system) {
     /* get the initial energy of the system */
     system->step = 0;
     initial_energy = energy(system);
+    if (system->hip_error) return -1; /* device failure: not a property of the configuration */
     /* be a bit forgiving of the initial state */
     if (!isfinite(initial_energy)) initial_energy = system->observables->energy = MAXVALUE;
 
@@ -391,6 +392,10 @@ int mc(system_t *system) {
         make_move(system);
         /* calculate the energy change */
         final_energy = energy(system);
+        if (system->hip_error) { /* a device / ABI failure is never turned into a rejected move */
+            error("MC: the device engine failed, stopping the chain\n");
+            return -1;
+        }
         /* treat a bad contact as a reject */
         if (!isfinite(final_energy)) {
             system->observables->energy = MAXVALUE;

@@ -128,6 +128,10 @@ typedef struct _system {
      * displaces or puts back (hip_note_touched); while hip_in_sync holds, energy() looks at those only instead
      * of walking all lists.  Anything else that edits the lists clears hip_in_sync (hip_note_list_changed). */
     int hip_in_sync, hip_ntouched;
+    /* Device / ABI failure of the last energy(): its own channel, NOT a Monte Carlo reject.  energy() still
+     * returns NAN (the double has no room for an error), but mc() and host_mc_steps() look here first and
+     * stop with -1; only a call that succeeded and produced a non-finite energy is a "bad contact". */
+    int hip_error;
     /* the movable (non-frozen) molecules in list order and each one's predecessor in the list, so that
      * checkpoint() need not walk the list twice per step; rebuilt after insertions / removals */
     struct _molecule **movable, **movable_prev;

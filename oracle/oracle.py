@@ -10,7 +10,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "libmpmc_oracle.so")
+# MPMC_ORACLE_LIB: the sanitizer build (make -C oracle asan) for tests/run_asan.sh
+_LIB = os.environ.get("MPMC_ORACLE_LIB") or os.path.join(_HERE, "libmpmc_oracle.so")
 
 
 class OrcParams(C.Structure):
