@@ -4,14 +4,30 @@
 One "step" = one single-molecule displacement (translate + rotate, reference
 src/mc/mc_moves.c:378-488) + one energy() on the device through the C ABI + Metropolis
 (reference src/mc/mc.c:294-353), exactly what the reference does per step; the loop itself is the
-C host layer of mpmc_amd/host/ (system_t, energy(), checkpoint/make_move/restore), called via ctypes.  Workload: the
-4096-atom PCN-61 cell + 416 BSSP H2 of tests/golden/pcn61_bssp_4096.npz with the flags of the
-reference's sample_configs_gpu/3_PCN61/iter.inp run as NVT (Jacobi x4, cutoff 8 A, FH 4th order)
--- BASELINE.json configs[3]; `--workload` selects the synthetic boxes instead.
+C host layer of mpmc_amd/host/ (system_t, energy(), checkpoint/make_move/restore), called via ctypes.
+energy() is evaluated incrementally -- everything pairwise is resident and only what the moved
+molecule touches is recomputed, bit-identical to a full evaluation (the reference caches per pair
+too, pairs.c:238-249) -- and `full_rebuild_steps_per_s` in the line is the same chain with every
+cached unit rebuilt every step.  Workload: the 4096-atom PCN-61 cell + 416 BSSP H2 of
+tests/golden/pcn61_bssp_4096.npz with the flags of the reference's sample_configs_gpu/3_PCN61/iter.inp
+run as NVT (Jacobi x4, cutoff 8 A, FH 4th order) -- BASELINE.json configs[3]; `--workload` selects
+the synthetic boxes instead.
 
-Walkers are independent: rank r runs its own chain with seed+r on GPU r; the only
-collective is the sum of a small observable vector every `corrtime` steps (RCCL over xGMI via
-torch.distributed, backend "nccl").  Prints ONE JSON line on rank 0.
+Walkers are independent: rank r runs its own chain with seed + r on GPU r; the only
+collective is the sum of a small observable vector every `corrtime` steps, through the C ABI's RCCL
+entry (mpmc_hip_allreduce_observables_begin/_end: what the reference's C mc() would call in place of
+MPI_Gather, mc.c:417-432).  torch.distributed is only the launcher's barrier / max-over-ranks clock.
+
+`python bench.py --gpus N` with N > 1 and no launcher environment starts the N ranks itself (child
+processes, before this process has imported torch or touched HIP) and relays rank 0's JSON line; under
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` it is one of the ranks.
+`--gpus` must equal WORLD_SIZE.  Prints ONE JSON line on rank 0.
+
+Measurement layout: the timed region carries NO events or probes (value does not depend on how the
+roofline is sampled); afterwards, untimed: (1) a roofline pass -- HIP events on the engine's own stream
+around every launch of the dominant kernel, raw mean, nothing subtracted; (2) a pass with every kernel
+class timed; (3) one full (non-incremental) evaluation for the pairs/s of the VALU-bound kernels; (4) the
+same chain with --full-rebuild semantics; (5) the CPU baseline (rank 0, N = 1 only).
 
 A/B switches (none changes what is computed; see include/mpmc_hip.h for the engine options behind them):
   --expanded-matrix / --full-sweep / --full-rebuild, --uvt, --walkers-per-gpu W, and the environment variables
@@ -20,20 +36,115 @@ A/B switches (none changes what is computed; see include/mpmc_hip.h for the engi
   energy(): printed to stderr when the contexts are destroyed).
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VALU_PEAK = 78.6e12   # MI355X fp64 vector peak, FLOP/s (256 CUs x 4 SIMD x 16 lanes x 2 x 2.4 GHz)
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--workload", default="pcn61_4096")
+    ap.add_argument("--corrtime", type=int, default=10)
+    ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-all-cores", type=int, default=1,
+                    help="also time one CPU walker per core on all cores (0 = skip)")
+    ap.add_argument("--walkers-per-gpu", type=int, default=1,
+                    help="independent walkers driven by each rank on its GPU, interleaved (default 1 = the headline "
+                         "definition: one Markov chain per GPU); value counts the steps of all of them")
+    ap.add_argument("--uvt", action="store_true",
+                    help="grand-canonical chain (insert / remove / displace) with the flags of the reference's "
+                         "3_PCN61/iter.inp (insert_probability 0.666, pressure 70 atm as the fugacity) instead of NVT")
+    ap.add_argument("--full-sweep", action="store_true", help="A/B: stream the full matrix instead of its upper triangle")
+    ap.add_argument("--full-rebuild", action="store_true", help="A/B: rebuild every cached unit from scratch every step")
+    ap.add_argument("--expanded-matrix", action="store_true",
+                    help="A/B: sweep over the expanded 3N x 3N matrix (72 B per pair) instead of pair coefficients (16 B)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="exercise the rank launcher and the seed/pooling bookkeeping WITHOUT a GPU (gloo, no energy is "
+                         "evaluated, value is null): what the CPU tests run")
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------------
+# launcher: N ranks as child processes, started before this process touches torch or HIP
+# ---------------------------------------------------------------------------------------------------
+def visible_gpus():
+    """GPUs this process could use, counted from sysfs (no HIP call, no torch import)."""
+    n = 0
+    for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            props = dict(line.split()[:2] for line in open(f) if len(line.split()) >= 2)
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0")) > 0 and int(props.get("gfx_target_version", "0")) > 0:
+            n += 1
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
+def launch_ranks(args):
+    """Start args.gpus ranks of this script and relay rank 0's JSON line.  Returns the exit code."""
+    n = args.gpus
+    if not args.launch_check:
+        have = visible_gpus()
+        if have < n:
+            sys.stderr.write("bench.py: --gpus %d needs %d GPUs, %d visible on this host (one walker per GPU; "
+                             "nothing was run)\n" % (n, n, have))
+            return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MPMC_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else None))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode]
+    deadline = time.time() + 120.0
+    for p in procs[1:]:
+        try:
+            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:
+            p.kill()  # exactly the PIDs started above
+            rcs.append(-9)
+    text = out.decode() if out else ""
+    sys.stdout.write(text)
+    sys.stdout.flush()
+    if any(rc != 0 for rc in rcs):
+        sys.stderr.write("bench.py: rank exit codes %s\n" % rcs)
+        return 1
+    lines = [ln for ln in text.splitlines() if ln.startswith("{")]
+    if len(lines) != 1 or json.loads(lines[0]).get("n_gpus") != n:
+        sys.stderr.write("bench.py: expected one JSON line with n_gpus = %d from rank 0\n" % n)
+        return 1
+    return 0
+
+
+# ---------------------------------------------------------------------------------------------------
+# workloads, CPU baseline
+# ---------------------------------------------------------------------------------------------------
 def load_workload(name):
+    import numpy as np
     from mpmc_amd import synth
 
     if name == "pcn61_4096":
@@ -55,18 +166,35 @@ def load_workload(name):
     raise SystemExit("unknown workload " + name)
 
 
-def cpu_baseline(system, flags, budget_s=20.0):
-    """The CPU oracle (a port of the reference path, including its per-pair caching between steps)
-    timed on this host, 1 core, bounded sample of the same workload: single-molecule moves + energy()."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_walker(workload, budget_s, core, max_steps=200):
+    """One CPU walker of the workload on one pinned core: the oracle (C restatement of the reference CPU path
+    with its per-pair caching between steps) driven with single-molecule moves.  Returns (steps, seconds)."""
+    import numpy as np
     from oracle import oracle
 
+    if core is not None:
+        try:
+            os.sched_setaffinity(0, {core})
+        except OSError:
+            pass
+    system, flags, _ = load_workload(workload)
     n = len(system["charge"])
     mol = np.asarray(system["molecule"])
     frozen = np.asarray(system["frozen"])
     starts = np.flatnonzero(np.r_[True, mol[1:] != mol[:-1]])
     ends = np.r_[starts[1:], n]
     movable = [(int(a), int(b)) for a, b in zip(starts, ends) if not frozen[a]]
-    rng = np.random.default_rng(7)
+    rng = np.random.default_rng(7 + (core or 0))
     s = dict(system)
     s["pos"] = np.array(system["pos"], dtype=np.float64)
     cache = oracle.Cache(n)
@@ -79,40 +207,108 @@ def cpu_baseline(system, flags, budget_s=20.0):
         oracle.energy(s, flags, cache=cache)
         nstep += 1
         el = time.perf_counter() - t0
-        if el > budget_s or nstep >= 200:
+        if el > budget_s or nstep >= max_steps:
             break
     cache.close()
-    return dict(value=nstep / el, unit="MC steps/s", cores=1, kind="port",
-                sample="%d single-molecule moves + energy() of the same workload by oracle/ (C restatement of the "
-                       "reference CPU path with its per-pair caching, gcc -O3, 1 thread), %.1f s" % (nstep, el))
+    return nstep, el
 
 
+def cpu_baseline(workload, budget_s=20.0, all_cores=True):
+    """The CPU path timed on this host (reported baseline, not the target): one pinned core, and -- clearly
+    labelled -- one walker per core on all cores."""
+    cores = sorted(os.sched_getaffinity(0))
+    saved = set(cores)
+    nstep, el = cpu_walker(workload, budget_s, cores[0])
+    os.sched_setaffinity(0, saved)
+    out = dict(value=nstep / el, unit="MC steps/s", cores=1, kind="port", cpu_model=cpu_model(),
+               pinned_core=cores[0],
+               sample="%d single-molecule moves + energy() of the same workload by oracle/ (C restatement of the "
+                      "reference CPU path with its per-pair caching, gcc -O3, 1 thread pinned to core %d), %.1f s"
+                      % (nstep, cores[0], el))
+    if all_cores and len(cores) > 1:
+        # throughput-equivalent line: one independent walker per core, all cores at once (fresh interpreters:
+        # nothing of this process's GPU state is inherited)
+        code = ("import sys, json; sys.path.insert(0, %r); import bench; "
+                "n, el = bench.cpu_walker(%r, %r, int(sys.argv[1]), 60); print(json.dumps([n, el]))"
+                % (ROOT, workload, budget_s * 0.6))
+        t0 = time.perf_counter()
+        procs = [subprocess.Popen([sys.executable, "-c", code, str(c)], stdout=subprocess.PIPE,
+                                  env=dict(os.environ, OMP_NUM_THREADS="1")) for c in cores]
+        rates = []
+        for p in procs:
+            o, _ = p.communicate()
+            if p.returncode == 0:
+                n, e = json.loads(o.decode().strip().splitlines()[-1])
+                rates.append(n / e)
+        out["all_cores"] = dict(value=sum(rates), unit="MC steps/s", cores=len(rates),
+                                note="one independent CPU walker per core x %d cores at once (sum of their rates; "
+                                     "not a parallel energy()); wall %.1f s" % (len(rates), time.perf_counter() - t0))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# the launch check: launcher + seeds + pooling, no GPU
+# ---------------------------------------------------------------------------------------------------
+def launch_check(args, rank, world):
+    import numpy as np
+    import torch.distributed as dist
+    from mpmc_amd import host, synth
+    from mpmc_amd.walkers import TorchReducer, WalkerAverages, walker_seed
+
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+    seed = walker_seed(args.seed, rank)
+    h = host.HostSystem(synth.s_pol(10), synth.FLAGS_POL_JACOBI, seed=seed)
+    avg = WalkerAverages(reducer=TorchReducer(dist) if world > 1 else None)
+    draws = []
+    for k in range(args.steps):
+        u = h.lib.host_get_rand(h.ptr)  # the walker's own stream (std::mt19937 seeded with seed + rank)
+        draws.append(u)
+        avg.add(u, 0.0, 0.0, 0.0, 0.0, 1.0)
+        if (k + 1) % args.corrtime == 0:
+            avg.reduce()
+    avg.reduce()
+    summ = avg.summary()
+    h.close()
+    first = [draws[0]]
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, draws[0])
+        first = gathered
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "MC steps/sec (polarizable, 4096 atoms)", "value": None, "unit": "MC steps/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "launch_check": True,
+                          "seeds": [walker_seed(args.seed, r) for r in range(world)], "first_draws": first,
+                          "pooled_samples": summ["samples"], "pooled_mean": summ["energy"]}))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+# ---------------------------------------------------------------------------------------------------
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--workload", default="pcn61_4096")
-    ap.add_argument("--corrtime", type=int, default=10)
-    ap.add_argument("--seed", type=int, default=1234)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--walkers-per-gpu", type=int, default=1,
-                    help="independent walkers driven by each rank on its GPU, interleaved (default 1 = the headline "
-                         "definition: one Markov chain per GPU); value counts the steps of all of them")
-    ap.add_argument("--uvt", action="store_true",
-                    help="grand-canonical chain (insert / remove / displace) with the flags of the reference's "
-                         "3_PCN61/iter.inp (insert_probability 0.666, pressure 70 atm as the fugacity) instead of NVT")
-    ap.add_argument("--full-sweep", action="store_true", help="A/B: stream the full matrix instead of its upper triangle")
-    ap.add_argument("--full-rebuild", action="store_true", help="A/B: rebuild A from scratch every step")
-    ap.add_argument("--expanded-matrix", action="store_true",
-                    help="A/B: sweep over the expanded 3N x 3N matrix (72 B per pair) instead of pair coefficients (16 B)")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))  # nothing GPU-related has been imported or initialised yet
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE = %d ranks (one walker per GPU: "
+                         "they must agree)" % (args.gpus, world))
+    if args.launch_check:
+        sys.exit(launch_check(args, rank, world))
+
+    import numpy as np
     import torch
 
+    if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
+        raise SystemExit("bench.py: rank %d needs GPU %d; %d visible (this engine has no CPU fallback)"
+                         % (rank, local_rank, torch.cuda.device_count() if torch.cuda.is_available() else 0))
     dist = None
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:  # under torchrun, also with a single rank
         import torch.distributed as dist
@@ -122,39 +318,37 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     from mpmc_amd import host
-    from mpmc_amd.walkers import WalkerAverages
+    from mpmc_amd.walkers import AbiReducer, WalkerAverages, walker_seed
 
     system, flags, label = load_workload(args.workload)
     n = len(system["charge"])
     # host control stays in C: system_t + energy() + the NVT chain of mpmc_amd/host/ drive the engine through the C ABI
     extra = {"ensemble": "uvt", "insert_probability": 0.666, "pressure": 70.0} if args.uvt else None
     W = max(1, args.walkers_per_gpu)
-    chains = [host.HostSystem(system, flags, device=local_rank, seed=args.seed + rank * W + w, extra=extra)
+    chains = [host.HostSystem(system, flags, device=local_rank, seed=walker_seed(args.seed, rank, W, w), extra=extra)
               for w in range(W)]
     chain = chains[0]
-    avg = WalkerAverages(dist=dist, device=dev)
     for ch in chains:
         ch.energy()  # creates the device context, uploads the configuration
-    if os.environ.get("MPMC_OVERLAP"):
-        chain.energy()
-        chain.set_option("overlap_streams", int(os.environ["MPMC_OVERLAP"]))
-    if os.environ.get("MPMC_SIDE_AFTER"):
-        chain.energy()
-        chain.set_option("side_after", int(os.environ["MPMC_SIDE_AFTER"]))
-    if os.environ.get("MPMC_STEP_GRAPH"):
-        chain.energy()
-        chain.set_option("step_graph", int(os.environ["MPMC_STEP_GRAPH"]))
-    if os.environ.get("MPMC_SYM_MODE"):
-        chain.energy()
-        chain.set_option("sym_mode", int(os.environ["MPMC_SYM_MODE"]))
-    if os.environ.get("MPMC_GS_DEBUG"):
-        chain.energy()
-        chain.set_option("persistent_gs", int(os.environ["MPMC_GS_DEBUG"]))
+    # ---- walker pooling through the C ABI: rank 0 makes the RCCL id, the launcher's process group hands it round
+    rccl_ranks = 1
+    if world > 1:
+        ids = [host.walkers_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        chain.walkers_init(world, rank, ids[0])
+        rccl_ranks = world
+    avg = WalkerAverages(reducer=AbiReducer(chain) if world > 1 else None)
+
+    for var, opt in (("MPMC_OVERLAP", "overlap_streams"), ("MPMC_SIDE_AFTER", "side_after"),
+                     ("MPMC_STEP_GRAPH", "step_graph"), ("MPMC_SYM_MODE", "sym_mode"), ("MPMC_GS_DEBUG", "persistent_gs")):
+        if os.environ.get(var):
+            chain.set_option(opt, int(os.environ[var]))
     if args.full_sweep or args.full_rebuild or args.expanded_matrix:
-        chain.energy()  # creates the device context
-        chain.set_option("symmetric_sweep", 0 if args.full_sweep else 1)
-        chain.set_option("incremental_amatrix", 0 if args.full_rebuild else 1)
-        chain.set_option("pair_coefficients", 0 if (args.expanded_matrix or args.full_sweep) else 1)
+        for ch in chains:
+            ch.set_option("symmetric_sweep", 0 if args.full_sweep else 1)
+            ch.set_option("incremental_amatrix", 0 if args.full_rebuild else 1)
+            ch.set_option("incremental_pairs", 0 if args.full_rebuild else 1)
+            ch.set_option("pair_coefficients", 0 if (args.expanded_matrix or args.full_sweep) else 1)
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -172,7 +366,7 @@ def main():
         while done < nsteps:
             k = min(args.corrtime, nsteps - done)
             if W == 1:
-                acc = chain.mc_steps(k)
+                acc = chain.mc_steps(k)  # raises on a device / ABI failure: never counted as rejected moves
             elif pool is None:
                 acc = host.mc_steps_multi(chains, k)  # one host thread feeds all walkers
             else:
@@ -185,68 +379,108 @@ def main():
             # walker averaging every corrtime (reference mc.c:417-432: MPI_Gather of observables)
             avg.reduce()
 
+    for ch in chains:
+        ch.set_option("timing", 0)  # no events anywhere near the timed region
     run(args.warmup)
-    # timed region: HIP events around the dominant (sweep) kernel only -- every event pair costs a few
-    # microseconds of stream time, so the per-class breakdown is taken in a separate, untimed pass below
-    chain.set_option("timing", 1)
-    # sampled calls cost ~80 us extra (event pairs on the stream + reading them back): every 32nd call, or every
-    # 4th in short runs so that a handful of sweeps is still sampled
-    chain.set_option("timing_interval", 32 if args.steps >= 128 else 4)
-    chain.enable_timing(True)
     sync()
     t0 = time.perf_counter()
     run(args.steps)
     avg.summary()  # completes the last (asynchronous) walker all-reduce inside the timed region
     sync()
     elapsed = time.perf_counter() - t0
-    acc = chain.timings()
-    nb = max(10, min(50, args.steps))
-    chain.set_option("timing", 2)
-    chain.enable_timing(True)
-    chain.mc_steps(nb)
-    brk = chain.timings()
-    chain.set_option("timing", 1)
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
 
+    # ---- untimed pass 1: the dominant kernel under HIP events on the engine's stream, every launch, raw mean
+    nprobe = 48
+    chain.set_option("timing", 1)
+    chain.set_option("timing_interval", 1)
+    chain.enable_timing(True)
+    chain.mc_steps(nprobe)
+    acc = chain.timings()
+    # ---- untimed pass 2: every kernel class
+    nb = 32
+    chain.set_option("timing", 2)
+    chain.enable_timing(True)
+    chain.mc_steps(nb)
+    brk = chain.timings()
+    # ---- untimed pass 3: one full (non-incremental) evaluation: the VALU-bound pair / field kernels over all tiles
+    chain.set_option("incremental_pairs", 0)
+    chain.enable_timing(True)
+    chain.mc_steps(4)
+    full = chain.timings()
+    chain.set_option("incremental_pairs", 1)
+    # ---- untimed pass 4: the same chain with every cached unit rebuilt every step
+    chain.set_option("timing", 0)
+    chain.set_option("incremental_amatrix", 0)
+    chain.set_option("incremental_pairs", 0)
+    nfr = max(10, min(200, args.steps // 4))
+    chain.mc_steps(5)
+    torch.cuda.synchronize(dev)
+    tf0 = time.perf_counter()
+    chain.mc_steps(nfr)
+    torch.cuda.synchronize(dev)
+    full_rebuild_rate = nfr / (time.perf_counter() - tf0)
+
     if rank == 0:
         value = world * W * args.steps / elapsed
-        # event pairs bracket the sweep kernel on every 32nd call of the timed region (every 4th in runs < 128 steps); an EMPTY pair recorded on
-        # the same calls measures what the two event records themselves add, and is subtracted
         sweep_raw_ms = acc["sweep_ms"] / max(1, acc["sweep_count"])
         event_pair_ms = acc["event_pair_ms"] / max(1, acc["event_pair_count"])
-        sweep_avg_ms = max(sweep_raw_ms - event_pair_ms, 0.0)
         # algorithmic bytes of one sweep launch (pair_sweep_kernel): one {c3, c5} coefficient pair (16 B, fp64)
         # per unordered pair of polarizable sites, read once, + coordinates and dipoles in, field out.
         # (sites with alpha = 0 carry no dipole, so neither their rows nor their columns exist)
         n_pol = int(np.count_nonzero(np.asarray(system["alpha"]) != 0.0))
         m3 = 3.0 * n_pol
         gs = bool(flags.get("polar_gs") or flags.get("polar_gs_ranked"))
-        expanded = args.expanded_matrix or args.full_sweep or gs
+        expanded = (args.expanded_matrix or args.full_sweep) and not gs
         sym_off = ((n_pol + 127) // 128 * 128) < 2048  # size threshold of the symmetric expanded-matrix kernel
-        if not expanded:
+        nblk = (n_pol + 63) // 64
+        if gs:
+            # one exact Gauss-Seidel sweep = upper-triangle product (pair_upper_kernel) + persistent lower-triangle
+            # solve (gs_chain_kernel): every {c3, c5} pair coefficient once (16 B per unordered pair) + the cached
+            # inverse of every diagonal block (192 x 192 lower triangle, fp64) + vectors
+            sweep_bytes = n_pol * (n_pol - 1) / 2 * 16 + nblk * (192 * 193 / 2) * 8 + 5 * m3 * 8
+            kernel_name = "pair_upper_kernel + gs_chain_kernel (one Gauss-Seidel sweep)"
+        elif not expanded:
             sweep_bytes = n_pol * (n_pol - 1) / 2 * 16 + 3 * m3 * 8
             kernel_name = "pair_sweep_kernel"
-        elif gs:  # exact Gauss-Seidel walks the expanded matrix: upper GEMV + persistent lower-triangle kernel
-            sweep_bytes = m3 * m3 * 8 + 5 * m3 * 8
-            kernel_name = "gs_upper_kernel + gs_persistent_kernel"
         elif args.full_sweep or sym_off:
             sweep_bytes = m3 * m3 * 8 + 5 * m3 * 8
             kernel_name = "sweep_kernel<Jacobi>"
         else:  # upper triangle of the expanded matrix
             sweep_bytes = m3 * (m3 + 1) / 2 * 8 + 3 * m3 * 8
             kernel_name = "symv_kernel"
-        achieved = sweep_bytes / (sweep_avg_ms * 1e-3) / 1e9 if sweep_avg_ms > 0 else 0.0
+        achieved = sweep_bytes / (sweep_raw_ms * 1e-3) / 1e9 if sweep_raw_ms > 0 else 0.0
+        # what the committed rocprofv3 profile of this command says (profiles/run_profile.sh writes it)
         traffic = None
+        rocprof_ms = None
         pmc = os.path.join(ROOT, "profiles", "sweep_pmc_latest.json")
         if os.path.exists(pmc) and args.workload == "pcn61_4096":
             try:
                 rec = json.load(open(pmc))
-                traffic = rec.get("hbm_bytes_per_launch") if kernel_name.split("<")[0] in rec.get("kernel", "") else None
+                if kernel_name.split("<")[0].split(" ")[0] in rec.get("kernel", ""):
+                    traffic = rec.get("hbm_bytes_per_launch")
+                    rocprof_ms = rec.get("rocprof_avg_launch_ms")
             except Exception:
                 traffic = None
+        # VALU-bound kernels over ALL tiles (pass 3): pairs/s and an estimate of the fp64 vector peak they use.
+        # Per pair the screen costs ~31 fp32 operations (counted as 15.5 fp64-equivalents at the 2:1 rate); the ~3 %
+        # of pairs inside the cutoff + margin pay the exact path: minimum image 46 + LJ/FH4 ~70 + erfc/exp ~60 fp64
+        # operations for the pair kernel, 46 + ~25 for the bare-field kernel.  Estimates, stated as such.
+        npair = n * (n - 1) / 2.0
+        pair_s = full["pair_ms"] / 4 * 1e-3
+        field_s = full["field_ms"] / 4 * 1e-3
+        valu = {}
+        if pair_s > 0:
+            valu["pair_rd_es_kernel"] = dict(pairs_per_s=npair / pair_s, ms_full_pass=pair_s * 1e3,
+                                             est_flop_per_pair=15.5 + 0.03 * 176,
+                                             est_frac_fp64_valu_peak=npair * (15.5 + 0.03 * 176) / pair_s / FP64_VALU_PEAK)
+        if field_s > 0:
+            valu["static_field_kernel"] = dict(pairs_per_s=2 * npair / field_s, ms_full_pass=field_s * 1e3,
+                                               est_flop_per_pair=15.5 + 0.03 * 71,
+                                               est_frac_fp64_valu_peak=2 * npair * (15.5 + 0.03 * 71) / field_s / FP64_VALU_PEAK)
         out = {
             "metric": "MC steps/sec (polarizable, 4096 atoms)",
             "value": value,
@@ -262,21 +496,35 @@ def main():
             "data": "synthetic" if args.workload != "pcn61_4096" else
                     "reference sample geometry (PCN-61 cell carved from sample_configs_gpu/3_PCN61/input.pdb), "
                     "random MC moves",
-            "config": {"workload": label + (" [UVT: insert/remove/displace]" if args.uvt else ""), "n_atoms": n, "n_polarizable": n_pol, "walkers": world * W, "corrtime": args.corrtime,
-                       "parallelism": "%d independent walkers, %d per GPU" % (world * W, W)},
+            "config": {"workload": label + (" [UVT: insert/remove/displace]" if args.uvt else "") +
+                                   ("; energy() rebuilt from scratch every step" if args.full_rebuild else
+                                    "; energy() incremental (bit-identical to full)"),
+                       "n_atoms": n, "n_polarizable": n_pol, "walkers": world * W, "corrtime": args.corrtime,
+                       "parallelism": "%d independent walkers, %d per GPU" % (world * W, W),
+                       "collective": "mpmc_hip_allreduce_observables_begin/_end (C ABI, RCCL) every corrtime",
+                       "rccl_ranks": rccl_ranks},
+            "full_rebuild_steps_per_s": full_rebuild_rate,
             "roofline": {"kernel": kernel_name + " (Thole field / dipole sweep)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "avg_launch_ms": sweep_avg_ms, "avg_launch_ms_with_event_pair": sweep_raw_ms,
-                         "event_pair_ms": event_pair_ms, "launches": acc["sweep_count"],
+                         "avg_launch_ms": sweep_raw_ms, "launches": acc["sweep_count"],
+                         "event_pair_ms": event_pair_ms,
+                         "rocprof_avg_launch_ms": rocprof_ms,
                          "algorithmic_bytes_per_launch": sweep_bytes,
                          # SURVEY 8(d) asks for these two beside a sweep that does not stream a stored matrix:
-                         "pairs_per_s": (n_pol * (n_pol - 1) / 2) / (sweep_avg_ms * 1e-3) if sweep_avg_ms > 0 else 0.0,
-                         "effective_GBps_reference_layout": ((m3 * m3 * 8) / (sweep_avg_ms * 1e-3) / 1e9
-                                                             if sweep_avg_ms > 0 else 0.0),
-                         "note": "achieved = bytes this design moves (16 B per unordered pair); "
+                         "pairs_per_s": (n_pol * (n_pol - 1) / 2) / (sweep_raw_ms * 1e-3) if sweep_raw_ms > 0 else 0.0,
+                         "effective_GBps_reference_layout": ((m3 * m3 * 8) / (sweep_raw_ms * 1e-3) / 1e9
+                                                             if sweep_raw_ms > 0 else 0.0),
+                         "note": "avg_launch_ms = raw mean of HIP-event pairs on the engine's stream around every launch "
+                                 "of the kernel in a separate untimed pass of %d steps (nothing subtracted: an event pair "
+                                 "itself adds event_pair_ms, so this is an upper bound of the kernel time and frac a lower "
+                                 "bound; rocprof_avg_launch_ms is the committed rocprofv3 mean of the same command); "
+                                 "achieved = bytes this design moves (16 B per unordered pair); "
                                  "effective_GBps_reference_layout prices the same time at the reference's (3N)^2 x 8 B "
-                                 "matrix and is not a bandwidth claim"},
+                                 "matrix and is not a bandwidth claim; the 87 MB coefficient set is re-read every sweep and "
+                                 "fits the 256 MB Infinity Cache, so part of the traffic may be served on-die (FETCH_SIZE "
+                                 "counts memory-side requests including such hits)" % nprobe},
+            "valu_kernels": valu,
             "device_ms_per_step": dict({k: brk[k] / nb for k in
                                         ("pair_ms", "recip_ms", "field_ms", "amatrix_ms", "sweep_ms", "palmo_ms",
                                          "other_ms", "total_ms")},
@@ -284,11 +532,12 @@ def main():
             "walker_averages": avg.summary(),
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(system, flags)
+            out["cpu_baseline"] = cpu_baseline(args.workload, all_cores=bool(args.cpu_all_cores))
         print(json.dumps(out))
     for ch in chains:
         ch.close()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

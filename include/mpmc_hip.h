@@ -196,7 +196,15 @@ int mpmc_hip_get_timings(mpmc_hip_ctx *ctx, mpmc_hip_timings *t);
 int mpmc_hip_comm_unique_id(unsigned char id[128]);
 int mpmc_hip_comm_create(mpmc_hip_comm **comm, mpmc_hip_ctx *ctx, int nranks, int rank,
                          const unsigned char id[128]);
+int mpmc_hip_comm_size(const mpmc_hip_comm *comm);
+int mpmc_hip_comm_rank(const mpmc_hip_comm *comm);
+/* Sum of `values[0..count)` (count <= 64) over all walkers, in place; blocking, like the MPI_Gather it replaces. */
 int mpmc_hip_allreduce_observables(mpmc_hip_comm *comm, double *values, int count);
+/* The same in two halves on the communicator's own stream: _begin copies `values` and starts the collective,
+ * _end waits and writes the sums.  The averages are reported only, never fed back into the chain, so the
+ * energy() calls of the next corrtime interval can run in between.  One collective in flight per communicator. */
+int mpmc_hip_allreduce_observables_begin(mpmc_hip_comm *comm, const double *values, int count);
+int mpmc_hip_allreduce_observables_end(mpmc_hip_comm *comm, double *values);
 void mpmc_hip_comm_destroy(mpmc_hip_comm *comm);
 
 #ifdef __cplusplus

@@ -1726,9 +1726,13 @@ extern "C" int mpmc_hip_get_timings(mpmc_hip_ctx *c, mpmc_hip_timings *t) {
 // ------------------------------------------------------------------------------------------
 struct mpmc_hip_comm {
     ncclComm_t nccl = nullptr;
-    mpmc_hip_ctx *ctx = nullptr;
+    int device = 0;                // (not the context: a caller may replace its context, e.g. when uvt outgrows it)
+    hipStream_t stream = nullptr;  // of its own: the collective never queues behind (or in front of) an energy()
     double *d_buf = nullptr;
+    double *h_buf = nullptr;       // pinned staging, so that both copies are truly asynchronous
     int cap = 0;
+    int nranks = 1, rank = 0;
+    int pending = 0;               // doubles of the all-reduce in flight (0: none)
 };
 
 struct Rccl {
@@ -1779,7 +1783,9 @@ extern "C" int mpmc_hip_comm_create(mpmc_hip_comm **out, mpmc_hip_ctx *ctx, int 
     if (load_rccl()) return -1;
     HIPCHK(hipSetDevice(ctx->device));
     mpmc_hip_comm *cm = new mpmc_hip_comm();
-    cm->ctx = ctx;
+    cm->device = ctx->device;
+    cm->nranks = nranks;
+    cm->rank = rank;
     ncclUniqueId u;
     memcpy(u.internal, id, 128);
     const ncclResult_t rc = g_rccl.CommInitRank(&cm->nccl, nranks, u, rank);
@@ -1788,28 +1794,59 @@ extern "C" int mpmc_hip_comm_create(mpmc_hip_comm **out, mpmc_hip_ctx *ctx, int 
         return rccl_fail("ncclCommInitRank", rc);
     }
     cm->cap = 64;
+    HIPCHK(hipStreamCreateWithFlags(&cm->stream, hipStreamNonBlocking));
     HIPCHK(hipMalloc((void **)&cm->d_buf, cm->cap * sizeof(double)));
+    HIPCHK(hipHostMalloc((void **)&cm->h_buf, cm->cap * sizeof(double), hipHostMallocDefault));
     *out = cm;
     return 0;
 }
 
-// sum over walkers of a small observable vector (<= 64 doubles), in place
-extern "C" int mpmc_hip_allreduce_observables(mpmc_hip_comm *cm, double *values, int count) {
+extern "C" int mpmc_hip_comm_size(const mpmc_hip_comm *cm) { return cm ? cm->nranks : 0; }
+extern "C" int mpmc_hip_comm_rank(const mpmc_hip_comm *cm) { return cm ? cm->rank : -1; }
+
+// Sum over walkers of a small observable vector (<= 64 doubles), in two halves: _begin copies the values out
+// of the caller's buffer and launches copy-in / all-reduce / copy-out on the communicator's own stream, _end
+// waits for them and writes the sums.  The averages are only reported, never fed back into the chains, so a
+// caller can run the next corrtime interval's energy() calls in between (the reference blocks in MPI_Gather,
+// mc.c:431).  One collective in flight per communicator.
+extern "C" int mpmc_hip_allreduce_observables_begin(mpmc_hip_comm *cm, const double *values, int count) {
     if (!cm || !values || count <= 0 || count > cm->cap) return fail("MPMC_HIP: allreduce: bad arguments");
-    mpmc_hip_ctx *c = cm->ctx;
-    HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipMemcpyAsync(cm->d_buf, values, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (cm->pending) return fail("MPMC_HIP: allreduce_begin: the previous all-reduce has not been collected");
+    HIPCHK(hipSetDevice(cm->device));
+    memcpy(cm->h_buf, values, count * sizeof(double));
+    HIPCHK(hipMemcpyAsync(cm->d_buf, cm->h_buf, count * sizeof(double), hipMemcpyHostToDevice, cm->stream));
     const ncclResult_t rc =
-        g_rccl.AllReduce(cm->d_buf, cm->d_buf, (size_t)count, ncclFloat64, ncclSum, cm->nccl, c->stream);
+        g_rccl.AllReduce(cm->d_buf, cm->d_buf, (size_t)count, ncclFloat64, ncclSum, cm->nccl, cm->stream);
     if (rc != ncclSuccess) return rccl_fail("ncclAllReduce", rc);
-    HIPCHK(hipMemcpyAsync(values, cm->d_buf, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpyAsync(cm->h_buf, cm->d_buf, count * sizeof(double), hipMemcpyDeviceToHost, cm->stream));
+    cm->pending = count;
     return 0;
+}
+
+extern "C" int mpmc_hip_allreduce_observables_end(mpmc_hip_comm *cm, double *values) {
+    if (!cm || !values) return fail("MPMC_HIP: allreduce: bad arguments");
+    if (!cm->pending) return fail("MPMC_HIP: allreduce_end: no all-reduce in flight");
+    HIPCHK(hipSetDevice(cm->device));
+    const int count = cm->pending;
+    cm->pending = 0;
+    HIPCHK(hipStreamSynchronize(cm->stream));
+    memcpy(values, cm->h_buf, count * sizeof(double));
+    return 0;
+}
+
+// the blocking form, in place
+extern "C" int mpmc_hip_allreduce_observables(mpmc_hip_comm *cm, double *values, int count) {
+    if (mpmc_hip_allreduce_observables_begin(cm, values, count)) return -1;
+    return mpmc_hip_allreduce_observables_end(cm, values);
 }
 
 extern "C" void mpmc_hip_comm_destroy(mpmc_hip_comm *cm) {
     if (!cm) return;
+    hipSetDevice(cm->device);
+    if (cm->stream) hipStreamSynchronize(cm->stream);
     if (cm->nccl && g_rccl.CommDestroy) g_rccl.CommDestroy(cm->nccl);
     if (cm->d_buf) hipFree(cm->d_buf);
+    if (cm->h_buf) hipHostFree(cm->h_buf);
+    if (cm->stream) hipStreamDestroy(cm->stream);
     delete cm;
 }

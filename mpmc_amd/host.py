@@ -54,6 +54,13 @@ def load():
     lib.checkpoint.argtypes = [vp]
     lib.make_move.argtypes = [vp]
     lib.restore.argtypes = [vp]
+    lib.walkers_unique_id.argtypes = [vp]
+    lib.walkers_init.argtypes = [vp, C.c_int, C.c_int, vp]
+    lib.walkers_pool_begin.argtypes = [vp, vp, C.c_int]
+    lib.walkers_pool_end.argtypes = [vp, vp, C.c_int]
+    lib.walkers_finalize.argtypes = [vp]
+    lib.walkers_finalize.restype = None
+    lib.host_device_error.argtypes = [vp]
     _lib = lib
     return lib
 
@@ -76,6 +83,14 @@ def config_text(flags, extra=None):
     for k, v in (extra or {}).items():
         lines.append("%s %s" % (k, v))
     return "\n".join(lines) + "\n"
+
+
+def walkers_unique_id():
+    """128-byte RCCL id (made on rank 0, handed to the other ranks by the launcher)."""
+    buf = (C.c_ubyte * 128)()
+    if load().walkers_unique_id(buf) != 0:
+        raise engine.EngineError("walkers_unique_id: " + engine.load().mpmc_hip_last_error().decode())
+    return bytes(buf)
 
 
 def mc_steps_multi(walkers, nsteps):
@@ -133,6 +148,23 @@ class HostSystem:
         if r < 0:
             raise engine.EngineError(engine.load().mpmc_hip_last_error().decode())
         return r
+
+    # ---- walker pooling through the C ABI's RCCL entry (the reference's MPI_Gather, mc.c:417-432)
+    def walkers_init(self, nranks, rank, unique_id):
+        buf = (C.c_ubyte * 128).from_buffer_copy(bytes(unique_id))
+        if self.lib.walkers_init(self.ptr, int(nranks), int(rank), buf) != 0:
+            raise engine.EngineError("walkers_init: " + engine.load().mpmc_hip_last_error().decode())
+
+    def pool_begin(self, values):
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        if self.lib.walkers_pool_begin(self.ptr, v.ctypes.data, len(v)) != 0:
+            raise engine.EngineError("walkers_pool_begin: " + engine.load().mpmc_hip_last_error().decode())
+
+    def pool_end(self, count):
+        out = np.zeros(count)
+        if self.lib.walkers_pool_end(self.ptr, out.ctypes.data, count) != 0:
+            raise engine.EngineError("walkers_pool_end: " + engine.load().mpmc_hip_last_error().decode())
+        return out
 
     def positions(self):
         pos = np.zeros((self.natoms(), 3))

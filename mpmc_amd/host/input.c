@@ -451,6 +451,7 @@ void hip_free_shadow(system_t *system);
 void free_system(system_t *system) {
     if (!system) return;
     host_profile_report();
+    walkers_finalize(system);
     if (system->hip_ctx) mpmc_hip_destroy(system->hip_ctx);
     hip_free_shadow(system);
     free(system->movable);

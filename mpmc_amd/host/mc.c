@@ -355,6 +355,56 @@ static void update_averages(system_t *system) {
     a->counter += 1.0;
 }
 
+/* ---- walker pooling: the MPI_Gather of the reference (mc.c:417-432), over RCCL through the C ABI ---- */
+int walkers_unique_id(unsigned char id[128]) {
+    if (mpmc_hip_comm_unique_id(id)) {
+        error("MC: could not make a communicator id\n");
+        return -1;
+    }
+    return 0;
+}
+
+int walkers_init(system_t *system, int nranks, int rank, const unsigned char id[128]) {
+    if (nranks < 1 || rank < 0 || rank >= nranks) return -1;
+    system->walker_rank = rank;
+    system->walker_nranks = nranks;
+    if (nranks == 1) return 0; /* nothing to pool with */
+    if (!system->hip_ctx) {
+        error("MC: walkers_init needs the device context (call energy() first)\n");
+        return -1;
+    }
+    if (mpmc_hip_comm_create(&system->hip_comm, system->hip_ctx, nranks, rank, id)) {
+        char buf[2 * MAXLINE];
+        snprintf(buf, sizeof(buf), "MC: walkers_init: %s\n", mpmc_hip_last_error());
+        error(buf);
+        return -1;
+    }
+    return 0;
+}
+
+int walkers_pool_begin(system_t *system, const double *values, int count) {
+    if (count <= 0 || count > 64) return -1;
+    if (!system->hip_comm) { /* a single walker: the pooled sums are its own */
+        memcpy(system->walker_pool_buf, values, count * sizeof(double));
+        return 0;
+    }
+    return mpmc_hip_allreduce_observables_begin(system->hip_comm, values, count) ? -1 : 0;
+}
+
+int walkers_pool_end(system_t *system, double *values, int count) {
+    if (count <= 0 || count > 64) return -1;
+    if (!system->hip_comm) {
+        memcpy(values, system->walker_pool_buf, count * sizeof(double));
+        return 0;
+    }
+    return mpmc_hip_allreduce_observables_end(system->hip_comm, values) ? -1 : 0;
+}
+
+void walkers_finalize(system_t *system) {
+    if (system->hip_comm) mpmc_hip_comm_destroy(system->hip_comm);
+    system->hip_comm = NULL;
+}
+
 /* implements the Markov chain */
 int mc(system_t *system) {
     double initial_energy, final_energy;

@@ -137,6 +137,11 @@ typedef struct _system {
     struct _molecule **movable, **movable_prev;
     int nmovable, movable_cap, movable_valid;
     struct _molecule *hip_touched[8];
+    /* walker pooling over xGMI (replaces the reference's MPI_Gather, src/mc/mc.c:417-432): one communicator per
+     * walker process, created by walkers_init() from a 128-byte id that rank 0 made and the launcher handed round */
+    mpmc_hip_comm *hip_comm;
+    int walker_rank, walker_nranks;
+    double walker_pool_buf[64]; /* a single walker's "pooled" sums between pool_begin and pool_end */
     mpmc_hip_timings hip_timings_sum; /* accumulated over energy() calls since mc() started */
     int hip_timing;
     FILE *fp_energy;
@@ -175,6 +180,16 @@ molecule_t *copy_molecule(system_t *system, molecule_t *src);
 void free_molecule(system_t *system, molecule_t *molecule);
 void translate(system_t *system, molecule_t *molecule, pbc_t *pbc, double scale);
 void rotate(system_t *system, molecule_t *molecule, pbc_t *pbc, double scale);
+
+/* walker averaging (reference src/mc/mc.c:417-476: MPI_Gather + update_root_averages; here every rank gets the
+ * pooled sums).  walkers_unique_id() on rank 0, the launcher distributes the id, walkers_init() on every rank
+ * after its first energy() (the communicator lives on the engine's device); walkers_pool_begin()/_end() sum a
+ * short vector over all walkers.  With one rank (or before walkers_init) pooling is the identity. */
+int walkers_unique_id(unsigned char id[128]);
+int walkers_init(system_t *system, int nranks, int rank, const unsigned char id[128]);
+int walkers_pool_begin(system_t *system, const double *values, int count);
+int walkers_pool_end(system_t *system, double *values, int count);
+void walkers_finalize(system_t *system);
 
 /* output */
 void output(const char *msg);

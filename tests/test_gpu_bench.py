@@ -26,4 +26,25 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0.2 < rf["frac"] < 1.0
-    assert 4 <= rf["launches"] <= 20 * 4 and rf["launches"] % 4 == 0  # Jacobi x4 per sampled step, HIP events
+    assert rf["launches"] >= 4 and rf["launches"] % 4 == 0  # Jacobi x4 per step of the separate probe pass, HIP events
+    assert rf["avg_launch_ms"] > 0 and "incremental (bit-identical to full)" in d["config"]["workload"]
+    assert d["config"]["rccl_ranks"] == 1 and d["full_rebuild_steps_per_s"] > 10.0
+    for k in ("pair_rd_es_kernel", "static_field_kernel"):
+        assert d["valu_kernels"][k]["pairs_per_s"] > 1e9
+
+
+def test_two_walkers_pool_through_the_c_abi_collective():
+    """configs[4] in small: `bench.py --gpus 2` starts its two ranks itself, each walker on its own GPU, observables
+    pooled by mpmc_hip_allreduce_observables_begin/_end (RCCL).  Needs two GPUs: skipped on the one-GPU box."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    if bench.visible_gpus() < 2:
+        pytest.skip("needs 2 GPUs (RCCL refuses two ranks on one device)")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "5",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["config"]["rccl_ranks"] == 2 and d["config"]["walkers"] == 2
+    # one sample per corrtime interval per walker: warm-up 5 steps = 1 interval, 40 steps = 4 intervals
+    assert d["walker_averages"]["samples"] == 2 * 5

@@ -1,10 +1,16 @@
-"""The N > 1 path on CPU: two ranks (gloo), each an independent walker, pooled through the same
-WalkerAverages.reduce() that bench.py runs over RCCL on the GPUs."""
+"""The N > 1 path on CPU: two ranks (gloo), each an independent walker -- the C host layer's own chain
+mechanics (get_rand seeded with seed + rank, checkpoint / make_move / restore, Metropolis on the oracle's
+energy: the GPU engine is absent here, so the checker stands in for energy() in this test only) -- pooled
+through the same WalkerAverages.reduce() that bench.py runs through the C ABI's RCCL entry on the GPUs.
+Also: bench.py's own rank launcher (`--gpus N` without a launcher environment)."""
+import json
 import os
 import socket
 import subprocess
 import sys
 import textwrap
+
+import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -13,29 +19,59 @@ WORKER = textwrap.dedent("""
     import numpy as np
     sys.path.insert(0, %r)
     import torch.distributed as dist
-    from mpmc_amd.walkers import WalkerAverages
+    from mpmc_amd import host, synth
+    from mpmc_amd.walkers import WalkerAverages, TorchReducer, walker_seed
+    from oracle import oracle
+
+    def chain(seed, nsteps, corrtime, avg):
+        # one walker: the reference's loop (mc.c:294-353) on the C host layer's moves and random numbers
+        sysm = synth.s_pol(20)
+        flags = dict(synth.FLAGS_POL_JACOBI)
+        T = flags["temperature"]
+        h = host.HostSystem(sysm, flags, seed=seed, move_factor=0.3, rot_factor=0.3)
+        lib = h.lib
+        lib.host_init_chain_no_energy(h.ptr)
+        def energy():
+            s = dict(sysm); s["pos"] = h.positions()
+            return oracle.energy(s, flags)["energy"]
+        e_old = energy()
+        trace, acc = [], 0
+        for step in range(1, nsteps + 1):
+            lib.make_move(h.ptr)
+            e_new = energy()
+            bf = np.exp(-(e_new - e_old) / T) if np.isfinite(e_new) else 0.0
+            if lib.host_get_rand(h.ptr) < bf:
+                lib.checkpoint(h.ptr); e_old = e_new; acc += 1; ok = 1
+            else:
+                lib.restore(h.ptr); ok = 0
+            trace.append(e_old)
+            avg.add(e_old, 0.0, 0.0, 0.0, 10, ok)
+            if step %% corrtime == 0:
+                avg.reduce()
+        h.close()
+        return trace, acc
+
     dist.init_process_group(backend="gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    rng = np.random.default_rng(100 + rank)          # seed + rank, as the walkers do
-    avg = WalkerAverages(dist=dist)
-    mine = []
-    for step in range(1, 41):
-        e = -1000.0 + rng.normal()
-        mine.append(e)
-        avg.add(e, 0.5 * e, 0.3 * e, 0.2 * e, 4, step %% 2)
-        if step %% 10 == 0:
-            avg.reduce()
+    avg = WalkerAverages(reducer=TorchReducer(dist))
+    trace, acc = chain(walker_seed(4321, rank), 30, 10, avg)
     s = avg.summary()
-    # every rank must hold the same pooled result
     gathered = [None] * world
-    dist.all_gather_object(gathered, (s, mine))
+    dist.all_gather_object(gathered, (s, trace, acc))
     if rank == 0:
-        allv = np.concatenate([np.array(g[1]) for g in gathered])
-        assert all(abs(g[0]["energy"] - s["energy"]) == 0.0 for g in gathered)
-        assert s["samples"] == 40 * world
-        assert abs(s["energy"] - allv.mean()) < 1e-9
-        assert abs(s["energy_sdom"] - allv.std() / np.sqrt(len(allv))) < 1e-9
-        assert abs(s["polar_iterations"] - 4.0) < 1e-12 and abs(s["acceptance"] - 0.5) < 1e-12
+        # every rank holds the same pooled result ...
+        assert all(g[0] == s for g in gathered)
+        # ... the walkers are different chains (seed + rank) ...
+        assert gathered[0][1] != gathered[1][1]
+        # ... and the pooled averages are those of the two chains run one after the other in ONE process
+        solo = WalkerAverages()
+        ref = [chain(walker_seed(4321, r), 30, 10, solo) for r in range(world)]
+        assert [r[0] for r in ref] == [g[1] for g in gathered]      # same seeds => same trajectories, bit for bit
+        t = solo.summary()
+        assert s["samples"] == t["samples"] == 30 * world
+        for k in ("energy", "energy_sdom", "acceptance", "polar_iterations"):
+            assert abs(s[k] - t[k]) <= 1e-12 * max(1.0, abs(t[k])), (k, s[k], t[k])
+        assert avg.reductions == 3
         print("OK", json.dumps(s))
     dist.destroy_process_group()
 """) % ROOT
@@ -53,7 +89,7 @@ def test_two_walkers_pool_observables_over_gloo(tmp_path):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
            "127.0.0.1", "--master-port", str(free_port()), str(script)]
     env = dict(os.environ, OMP_NUM_THREADS="1")
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "OK" in out.stdout
 
@@ -68,3 +104,53 @@ def test_single_walker_needs_no_process_group():
     a.reduce()
     s = a.summary()
     assert s["samples"] == 2 and s["energy"] == -11.0 and s["acceptance"] == 0.5
+
+
+def _bench(*args, env=None, timeout=600):
+    e = dict(os.environ, OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), capture_output=True, text=True,
+                          timeout=timeout, env=e)
+
+
+def test_bench_gpus_2_spawns_two_ranks_by_itself():
+    """`python bench.py --gpus 2` with no launcher environment starts two ranks (children, before the parent touches
+    torch or HIP); --launch-check runs the launcher, the seed + rank bookkeeping and the pooling without a GPU."""
+    r = _bench("--gpus", "2", "--launch-check", "--steps", "20", "--corrtime", "5", "--seed", "99")
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["launch_check"] is True and d["value"] is None
+    assert d["seeds"] == [99, 100]
+    assert d["pooled_samples"] == 40                      # 20 draws of each of the 2 ranks, pooled over gloo
+    assert d["first_draws"][0] != d["first_draws"][1]     # seed + rank: different random streams
+    # rank r's first draw is the first draw of std::mt19937(seed + r) through the host layer
+    from mpmc_amd import host, synth
+
+    for rnk, want in enumerate(d["first_draws"]):
+        h = host.HostSystem(synth.s_pol(10), synth.FLAGS_POL_JACOBI, seed=99 + rnk)
+        assert h.lib.host_get_rand(h.ptr) == want
+        h.close()
+
+
+def test_bench_gpus_2_without_gpus_fails_loudly():
+    """No silent 1-walker run: on a host with fewer GPUs than --gpus the launcher refuses before starting anything."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    if bench.visible_gpus() >= 2:
+        import pytest
+
+        pytest.skip("this host has 2 GPUs")
+    r = _bench("--gpus", "2", "--steps", "5", "--warmup", "1")
+    assert r.returncode != 0
+    assert "needs 2 GPUs" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_refuses_gpus_that_disagree_with_world_size():
+    r = _bench("--gpus", "4", "--launch-check", env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "must agree" in (r.stderr + r.stdout)
