@@ -226,14 +226,28 @@ def cpu_baseline(workload, budget_s=20.0, all_cores=True):
                       "reference CPU path with its per-pair caching, gcc -O3, 1 thread pinned to core %d), %.1f s"
                       % (nstep, cores[0], el))
     if all_cores and len(cores) > 1:
-        # throughput-equivalent line: one independent walker per core, all cores at once (fresh interpreters:
-        # nothing of this process's GPU state is inherited)
+        # throughput-equivalent line: one independent walker per core, all cores of this job's CPU share at once
+        # (fresh interpreters: nothing of this process's GPU state is inherited).  The pool is sized to the share
+        # (16 cores per GPU on the bench boxes, whatever the affinity mask says) AND to memory: every walker holds
+        # its own pair cache and A matrix (~3 GB at 4096 atoms), and a host-memory overrun ends the whole box.
+        import resource
+
+        rss_gb = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1048576.0 + 0.5  # this process ran one walker
+        avail_gb = 0.0
+        try:
+            for line in open("/proc/meminfo"):
+                if line.startswith("MemAvailable"):
+                    avail_gb = float(line.split()[1]) / 1048576.0
+        except OSError:
+            pass
+        nproc = min(len(cores), 16, max(1, int(0.25 * avail_gb / rss_gb)))
+        use = cores[:nproc]
         code = ("import sys, json; sys.path.insert(0, %r); import bench; "
                 "n, el = bench.cpu_walker(%r, %r, int(sys.argv[1]), 60); print(json.dumps([n, el]))"
                 % (ROOT, workload, budget_s * 0.6))
         t0 = time.perf_counter()
         procs = [subprocess.Popen([sys.executable, "-c", code, str(c)], stdout=subprocess.PIPE,
-                                  env=dict(os.environ, OMP_NUM_THREADS="1")) for c in cores]
+                                  env=dict(os.environ, OMP_NUM_THREADS="1")) for c in use]
         rates = []
         for p in procs:
             o, _ = p.communicate()
@@ -241,8 +255,10 @@ def cpu_baseline(workload, budget_s=20.0, all_cores=True):
                 n, e = json.loads(o.decode().strip().splitlines()[-1])
                 rates.append(n / e)
         out["all_cores"] = dict(value=sum(rates), unit="MC steps/s", cores=len(rates),
+                                cores_in_affinity_mask=len(cores),
                                 note="one independent CPU walker per core x %d cores at once (sum of their rates; "
-                                     "not a parallel energy()); wall %.1f s" % (len(rates), time.perf_counter() - t0))
+                                     "not a parallel energy(); pool = min(cores in the mask, 16 = the CPU share of one "
+                                     "GPU, memory / 4)); wall %.1f s" % (len(rates), time.perf_counter() - t0))
     return out
 
 
