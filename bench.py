@@ -454,11 +454,12 @@ def main():
         sym_off = ((n_pol + 127) // 128 * 128) < 2048  # size threshold of the symmetric expanded-matrix kernel
         nblk = (n_pol + 63) // 64
         if gs:
-            # one exact Gauss-Seidel sweep = upper-triangle product (pair_upper_kernel) + persistent lower-triangle
-            # solve (gs_chain_kernel): every {c3, c5} pair coefficient once (16 B per unordered pair) + the cached
-            # inverse of every diagonal block (192 x 192 lower triangle, fp64) + vectors
-            sweep_bytes = n_pol * (n_pol - 1) / 2 * 16 + nblk * (192 * 193 / 2) * 8 + 5 * m3 * 8
-            kernel_name = "pair_upper_kernel + gs_chain_kernel (one Gauss-Seidel sweep)"
+            # gs_chain_kernel (the persistent lower-triangle launch of one exact Gauss-Seidel sweep): the {c3, c5}
+            # coefficients of every tile (t, s <= t-2) (16 B per pair), the expanded sub-diagonal tiles (t, t-1)
+            # (48 B per pair), the cached inverse of every diagonal block (32 x 9 x 64 doubles) and the vectors
+            sweep_bytes = (max(nblk - 1, 0) * max(nblk - 2, 0) / 2) * 4096 * 16 + max(nblk - 1, 0) * 4096 * 48 \
+                + nblk * 18432 * 8 + 6 * m3 * 8
+            kernel_name = "gs_chain_kernel"
         elif not expanded:
             sweep_bytes = n_pol * (n_pol - 1) / 2 * 16 + 3 * m3 * 8
             kernel_name = "pair_sweep_kernel"

@@ -406,8 +406,8 @@ __global__ __launch_bounds__(64 * kCoefWaves) void pair_sweep_kernel(const doubl
 // the 72 B per pair gs_upper_kernel reads from the expanded matrix.
 //   pair_upper_kernel:        grid = nt (nt + 1) / 2, block = 256  ->  Srow[tj][192 ti + 64 p + l]
 //   pair_upper_finish_kernel: grid = nvpad / 64, block = 64 x 16: y[3 i + p] = - sum_{tj >= t} Srow, zeros for
-//                             the padding blocks; with `arm` it also prepares the hand-off buffers of the
-//                             persistent lower-triangle kernel (sentinel pattern, flag words zero).
+//                             the padding blocks; with `arm` it also prepares the hand-off buffer of the
+//                             persistent lower-triangle kernel (sentinel pattern) and zeroes its ticket counter.
 // ---------------------------------------------------------------------------------------------
 template <int ORTHO>
 __global__ __launch_bounds__(64 * kCoefWaves) void pair_upper_kernel(const double2 *__restrict__ C, int nt, int ntld,
@@ -466,19 +466,15 @@ __global__ __launch_bounds__(64 * kCoefWaves) void pair_upper_kernel(const doubl
 __global__ __launch_bounds__(64 * kCoefFinishGroups) void pair_upper_finish_kernel(int nt, const double *__restrict__ Srow,
                                                                                     double *__restrict__ yout, int arm,
                                                                                     double *__restrict__ mu_new,
-                                                                                    double *__restrict__ ypart,
-                                                                                    unsigned *__restrict__ gsflags,
-                                                                                    int nflags) {
+                                                                                    unsigned *__restrict__ gsflags) {
     const int t = blockIdx.x;
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int i = 64 * t + lane;
-    if (arm) {  // this block's share of the hand-off buffers (192 doubles each), and the flag words
+    if (arm) {  // this block's share of the hand-off buffer (192 doubles) and the ticket counter; the error word
+                // (gsflags[1]) is sticky for the whole energy() call and is NOT touched here
         const double sentinel = __longlong_as_double(0x7ff8dead7ff8deadll);
-        if (threadIdx.x < 192) {
-            mu_new[192 * t + threadIdx.x] = sentinel;
-            ypart[192 * t + threadIdx.x] = sentinel;
-        }
-        if (t == 0 && (int)threadIdx.x < nflags) gsflags[threadIdx.x] = 0u;
+        if (threadIdx.x < 192) mu_new[192 * t + threadIdx.x] = sentinel;
+        if (t == 0 && threadIdx.x == 0) gsflags[0] = 0u;
     }
     __shared__ double part[kCoefFinishGroups][3][64];
     const size_t ncol = 3 * (size_t)kCoefTile * nt;

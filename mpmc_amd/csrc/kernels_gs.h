@@ -35,24 +35,11 @@ __device__ __forceinline__ double plain_distance(double dx, double dy, double dz
 
 // y_k = - sum_{j > k} T_kj mu_j : wave per atom, same streaming pattern as sweep_kernel but the
 // column range starts at the atom's own block column.  grid = npad/4, block = 256.
-// With `arm` set it also prepares the hand-off buffers of the persistent lower-triangle kernel that follows
-// (three fill launches per sweep otherwise): mu_new and ypart to the sentinel pattern, the flag words to 0.
 __global__ __launch_bounds__(256) void gs_upper_kernel(const double *__restrict__ A, int lda, int npad,
                                                         const double *__restrict__ mu_old,
-                                                        double *__restrict__ y, int arm, double *__restrict__ mu_new,
-                                                        double *__restrict__ ypart, unsigned *__restrict__ gsflags,
-                                                        int nflags) {
+                                                        double *__restrict__ y) {
     const int lane = threadIdx.x & 63;
     const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (arm) {
-        const int gid = blockIdx.x * 256 + threadIdx.x;  // 64 threads per atom: more than the 3 npad doubles
-        const double sentinel = __longlong_as_double(0x7ff8dead7ff8deadll);
-        if (gid < 3 * npad) {
-            mu_new[gid] = sentinel;
-            ypart[gid] = sentinel;
-        }
-        if (gid < nflags) gsflags[gid] = 0u;
-    }
     const double *a0 = A + (size_t)(3 * k) * lda;
     const double *a1 = a0 + lda;
     const double *a2 = a1 + lda;

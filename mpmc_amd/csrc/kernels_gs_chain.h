@@ -1,0 +1,445 @@
+// kernels_gs_chain.h -- the lower-triangle phase of the exact Gauss-Seidel sweep (polar_gs / polar_gs_ranked,
+// reference src/polarization/thole_iterative.c:27-59) as ONE persistent launch, with the serial forward
+// substitution of a 64-atom block replaced by a cached block inverse.
+//
+// In sweep order, block t of 64 atoms obeys (D = diag(alpha), L = strictly lower part of the block's own
+// dipole tensor, e = E_static, yU = -(upper triangle) mu_old from pair_upper_kernel):
+//     mu_t = D (e + yU - sum_{s<t} T(t,s) mu_s) - D L mu_t     <=>     mu_t = M_t v_t,
+//     v_t = D (e + yU - sum_{s<t} T(t,s) mu_s),      M_t = (I + D L)^-1   (192 x 192, unit lower triangular).
+// M_t depends only on the 64 atoms of its own block, so it is CACHED between MC steps exactly like the pair
+// coefficients and rebuilt only for the block(s) that hold a moved atom (gs_block_inverse_kernel: forward
+// substitution on the identity, one wave per column).  The sweep's critical path per block is then
+//     hand-off of mu_{t-1}  ->  T(t,t-1) mu_{t-1}  ->  M_t v_t       (two 64 x 64 block products)
+// instead of a 63-step dependent chain (8.5 us per block in round 1, ~2 us here).  The result is algebraically
+// the reference's; it differs from the literal substitution by rounding only (1e-13 relative, tests hold 1e-10).
+//
+// Work decomposition: ONE workgroup per 64-atom block, 8 waves, no separate spine / owner roles.  A workgroup
+// draws its block index t from a ticket counter when it STARTS, so it only ever waits for blocks whose
+// workgroups are already running or done: no co-residency assumption, no deadlock under any dispatch order or
+// oversubscription (several walkers on one GPU).  Workgroup t
+//   1. stages M_t in LDS (147 KB) and the neighbour tensor tile T(t,t-1) in registers (expanded, 6 doubles per
+//      pair, from gs_neighbor_tensor_kernel) -- nothing on the critical path touches HBM;
+//   2. for s = 0 .. t-2, as mu_s is published: acc += T(t,s) mu_s from the 16-B pair coefficients, geometry
+//      rebuilt in registers as in pair_sweep_kernel (lane = source atom, the target sums rotate across the
+//      lanes; forward and backward passes alternate so the sums end where they started); coefficients of the
+//      next tile are in flight while the current one is multiplied;
+//   3. on mu_{t-1}: neighbour product from registers, v_t, M_t v_t from LDS, publishes mu_t.
+// Hand-offs are data-is-the-flag (Guideline 16, R2 with the value as its own tag): mu_new is pre-filled with
+// a sentinel NaN pattern, the producer writes every double with one agent-scope (sc1, write-through) 8-byte
+// store, consumers poll their own element with agent-scope loads.  Every spin is bounded; a give-up sets a
+// STICKY error word (zeroed once per energy(), never by a sweep) that mpmc_hip_energy_end() turns into an error.
+// All sums have a fixed order: results do not depend on placement or timing.
+#pragma once
+#include "device_common.h"
+#include "kernels_gs.h"
+#include "kernels_coef.h"  // image_displacement, wave_rotate_down, the coefficient tile layout
+
+namespace mpmc {
+
+constexpr int kGsPairs = kGsBlock * (kGsBlock - 1) / 2;  // 2016 ordered pairs (row > column) of a block
+constexpr int kChainWaves = 8;
+constexpr int kChainThreads = 64 * kChainWaves;
+constexpr unsigned kGsSpinLimit = 1u << 22;  // ~3 s of polling; a legitimate wait is at most one sweep (< 1 ms)
+constexpr unsigned long long kGsSentinel = 0x7ff8dead7ff8deadull;  // a NaN no arithmetic produces
+
+// ---- cached block inverse M_t, "folded" so that one wave instruction is always fully used:
+//   group g (0..31), element e = 3 p + q (row component p, column component q), lane l:
+//     g <= 30:  l >  g : M[row atom l     ][column atom g     ]
+//               l <= g : M[row atom 63 - l][column atom 62 - g]
+//     g == 31:  l > 31 : M[row atom l][column atom 31],  l <= 31 : 0
+//   Minv[((t * 32 + g) * 9 + e) * 64 + l]
+// (column atom c has 63 - c rows below it: columns c and 62 - c together fill exactly 64 lanes.)
+constexpr int kMinvGroups = 32;
+constexpr int kMinvDoubles = kMinvGroups * 9 * 64;  // 18 432 per block (147 456 B)
+__device__ __forceinline__ int minv_index(int row, int col, int e) {  // row > col, atoms within the block
+    const int g = (col <= 31) ? col : 62 - col;
+    const int l = (col <= 31) ? row : 63 - row;
+    return (g * 9 + e) * 64 + l;
+}
+
+// ---- expanded neighbour tile T(t, t-1): target atom i of block t, source atom j of block t-1
+//   Tnb[((t * 64 + j) * 3 + h) * 64 + i] = double2 {xx,xy} (h = 0), {xz,yy} (h = 1), {yz,zz} (h = 2)
+constexpr int kTnbDouble2 = 64 * 3 * 64;  // per block (196 608 B)
+
+struct GsChain {
+    const double2 *C;  // pair-coefficient tiles of the view (kernels_coef.h)
+    int ntld, nb;
+    const double *px, *py, *pz, *alpha, *es;
+    const double *Minv;
+    const double2 *Tnb;
+    double *y;         // in: upper-triangle part (pair_upper_finish_kernel); out: E_induced at update time
+    double *mu_new;    // out; pre-filled with kGsSentinel
+    unsigned *flags;   // [0] ticket counter (zeroed per sweep), [1] sticky error word, [2..4] breadcrumbs
+    DevBox bx;
+    int fault_block;   // test hook: the workgroup of this block never publishes (-1 = off)
+};
+
+__device__ __forceinline__ void st_agent(double *p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// poll one double until it differs from the sentinel (agent-scope loads bypass the never-refreshed L1)
+__device__ __forceinline__ double poll_value(const double *p, unsigned *flags, bool &ok) {
+    const unsigned long long *q = reinterpret_cast<const unsigned long long *>(p);
+    for (unsigned it = 0; it < kGsSpinLimit; ++it) {
+        const unsigned long long v = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v != kGsSentinel) return __longlong_as_double((long long)v);
+        if ((it & 255u) == 255u && __hip_atomic_load(flags + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    if (__hip_atomic_exchange(flags + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        // first to give up: leave a breadcrumb (which workgroup, which thread, low address bits)
+        flags[2] = blockIdx.x;
+        flags[3] = threadIdx.x;
+        flags[4] = (unsigned)(reinterpret_cast<unsigned long long>(p) & 0xffffffffu);
+    }
+    ok = false;
+    return 0.0;
+}
+
+// 64-lane rotation by one the other way: lane l receives the value of lane (l - 1) & 63 (wave_ror:1)
+__device__ __forceinline__ double wave_rotate_up(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x13C, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x13C, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Expanded tensors of the sub-diagonal tiles (t, t-1), t = blk[b] (or every t >= 1 with nsel = 0).
+// grid = nsel or nb - 1; block = 256.  A tile is a pure function of its two blocks' coordinates.
+// ---------------------------------------------------------------------------------------------
+struct BlockList {
+    int n;
+    int blk[48];
+};
+
+template <int ORTHO>
+__global__ __launch_bounds__(256) void gs_neighbor_tensor_kernel(const double2 *__restrict__ C, int ntld,
+                                                                  const double *__restrict__ px,
+                                                                  const double *__restrict__ py,
+                                                                  const double *__restrict__ pz, DevBox bx, BlockList sel,
+                                                                  double2 *__restrict__ Tnb) {
+    const int t = (sel.n > 0) ? sel.blk[blockIdx.x] : (int)blockIdx.x + 1;
+    if (t < 1) return;
+    const double2 *tile = C + (size_t)((t - 1) * ntld + t) * (kCoefTile * kCoefTile);
+    double2 *out = Tnb + (size_t)t * kTnbDouble2;
+    const int i = threadIdx.x & 63;
+    const double xi = px[64 * t + i], yi = py[64 * t + i], zi = pz[64 * t + i];
+    for (int j = threadIdx.x >> 6; j < 64; j += 4) {
+        const int js = 64 * (t - 1) + j;
+        // row atom of the tile = source j (block t-1), column atom = target i: element (l = j, s = (i - j) & 63)
+        const double2 c = tile[((i - j) & 63) * 64 + j];
+        double dx, dy, dz;
+        image_displacement<ORTHO>(bx, px[js] - xi, py[js] - yi, pz[js] - zi, dx, dy, dz);
+        const double c3 = c.x, c5 = c.y;
+        out[(j * 3 + 0) * 64 + i] = make_double2(-3.0 * dx * dx * c5 + c3, -3.0 * dx * dy * c5);
+        out[(j * 3 + 1) * 64 + i] = make_double2(-3.0 * dx * dz * c5, -3.0 * dy * dy * c5 + c3);
+        out[(j * 3 + 2) * 64 + i] = make_double2(-3.0 * dy * dz * c5, -3.0 * dz * dz * c5 + c3);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// M_t = (I + D L)^-1 of block t = blk[blockIdx.y] (or blockIdx.y with nsel = 0): forward substitution on the
+// identity.  Columns are independent, so a block is spread over 16 workgroups (blockIdx.x = group of 4 column
+// atoms) of 12 waves (wave = one scalar column): lane b holds x_b, the column's 3 entries in atom b's rows; step a
+// forms x_a = -alpha_a sum_{b<a} T_ab x_b with a 64-lane reduction.  The block's tensors are expanded once into
+// LDS from the diagonal coefficient tile (packed lower triangle, 6 doubles per pair).
+// grid = (16, nsel or nb); block = 768; dynamic LDS = kInverseLds.
+// ---------------------------------------------------------------------------------------------
+constexpr int kInverseLds = (kGsPairs * 6 + 4 * 64) * 8;
+
+__device__ __forceinline__ double wave_sum_bcast(double v) {  // every lane gets the total, fixed order
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <int ORTHO>
+__global__ __launch_bounds__(768) void gs_block_inverse_kernel(const double2 *__restrict__ C, int ntld,
+                                                                const double *__restrict__ px,
+                                                                const double *__restrict__ py,
+                                                                const double *__restrict__ pz,
+                                                                const double *__restrict__ alpha, DevBox bx, BlockList sel,
+                                                                double *__restrict__ Minv) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *T6 = lds;                  // row a (1..63): offset 6 * a (a - 1) / 2, then [e][b], b < a
+    double *sx = lds + kGsPairs * 6;   // [64] x, y, z, alpha of the block
+    double *sy = sx + 64, *sz = sy + 64, *sal = sz + 64;
+    const int t = (sel.n > 0) ? sel.blk[blockIdx.y] : (int)blockIdx.y;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (w == 0) {
+        sx[lane] = px[64 * t + lane];
+        sy[lane] = py[64 * t + lane];
+        sz[lane] = pz[64 * t + lane];
+        sal[lane] = alpha[64 * t + lane];
+    }
+    __syncthreads();
+    // expand the strictly lower triangle: pair (a, b), a > b, is element (l = b, s = a - b) of the diagonal tile
+    const double2 *tile = C + (size_t)(t * ntld + t) * (kCoefTile * kCoefTile);
+    for (int s = 1 + w; s < 64; s += 12) {
+        const int b = lane, a = lane + s;
+        if (a < 64) {
+            const double2 c = tile[s * 64 + b];
+            double dx, dy, dz;
+            image_displacement<ORTHO>(bx, sx[b] - sx[a], sy[b] - sy[a], sz[b] - sz[a], dx, dy, dz);
+            const double c3 = c.x, c5 = c.y;
+            double *row = T6 + 3 * a * (a - 1);  // 6 * a (a - 1) / 2
+            row[0 * a + b] = -3.0 * dx * dx * c5 + c3;
+            row[1 * a + b] = -3.0 * dx * dy * c5;
+            row[2 * a + b] = -3.0 * dx * dz * c5;
+            row[3 * a + b] = -3.0 * dy * dy * c5 + c3;
+            row[4 * a + b] = -3.0 * dy * dz * c5;
+            row[5 * a + b] = -3.0 * dz * dz * c5 + c3;
+        }
+    }
+    __syncthreads();
+    const int c = 4 * blockIdx.x + w / 3, q = w % 3;  // this wave's column: atom c, component q
+    double x0 = 0.0, x1 = 0.0, x2 = 0.0;
+    if (lane == c) {
+        x0 = (q == 0) ? 1.0 : 0.0;
+        x1 = (q == 1) ? 1.0 : 0.0;
+        x2 = (q == 2) ? 1.0 : 0.0;
+    }
+    for (int a = c + 1; a < 64; ++a) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+        if (lane >= c && lane < a) {
+            const double *row = T6 + 3 * a * (a - 1) + lane;
+            const double xx = row[0], xy = row[a], xz = row[2 * a], yy = row[3 * a], yz = row[4 * a], zz = row[5 * a];
+            s0 = fma(xz, x2, fma(xy, x1, xx * x0));
+            s1 = fma(yz, x2, fma(yy, x1, xy * x0));
+            s2 = fma(zz, x2, fma(yz, x1, xz * x0));
+        }
+        s0 = wave_sum_bcast(s0);
+        s1 = wave_sum_bcast(s1);
+        s2 = wave_sum_bcast(s2);
+        if (lane == a) {
+            const double al = sal[a];
+            x0 = -al * s0;
+            x1 = -al * s1;
+            x2 = -al * s2;
+        }
+    }
+    if (lane > c) {
+        double *out = Minv + (size_t)t * kMinvDoubles;
+        out[minv_index(lane, c, 0 + q)] = x0;
+        out[minv_index(lane, c, 3 + q)] = x1;
+        out[minv_index(lane, c, 6 + q)] = x2;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The chain.  grid = nb workgroups, block = 512, dynamic LDS = kChainLds.
+// ---------------------------------------------------------------------------------------------
+// (all LDS is dynamic, so its base stays 16-byte aligned -- Guideline 17; the two control words sit at the end)
+constexpr int kChainLdsDoubles = kMinvDoubles + kChainWaves * 3 * 64 + 3 * 64 + 3 * 64 + 2;
+constexpr int kChainLds = kChainLdsDoubles * 8;  // 162 832 B of the 163 840 a workgroup may have
+
+template <int ORTHO>
+__global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *sM = lds;                                   // [32][9][64] folded inverse of this block
+    double *zred = sM + kMinvDoubles;                   // [8][3][64] per-wave partial sums
+    double *smu = zred + kChainWaves * 3 * 64;          // [3][64] dipoles of the source block just polled; later v_t
+    double *spos = smu + 3 * 64;                        // [3][64] coordinates of this (target) block
+    int &s_t = reinterpret_cast<int *>(spos + 3 * 64)[0];
+    int &s_ok = reinterpret_cast<int *>(spos + 3 * 64)[1];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+
+    if (tid == 0) {
+        s_t = (int)__hip_atomic_fetch_add(p.flags, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_ok = 1;
+    }
+    __syncthreads();
+    const int t = s_t;
+    if (t >= p.nb) return;
+    const size_t tsz = kCoefTile * kCoefTile;
+
+    // ---- stage M_t (folded layout, 16-B loads) and the target block's coordinates
+    {
+        const double2 *src = reinterpret_cast<const double2 *>(p.Minv + (size_t)t * kMinvDoubles);
+        double2 *dst = reinterpret_cast<double2 *>(sM);
+        double2 r[kMinvDoubles / 2 / kChainThreads];
+#pragma unroll
+        for (int k = 0; k < kMinvDoubles / 2 / kChainThreads; ++k) r[k] = src[k * kChainThreads + tid];
+#pragma unroll
+        for (int k = 0; k < kMinvDoubles / 2 / kChainThreads; ++k) dst[k * kChainThreads + tid] = r[k];
+    }
+    if (tid < 192) {
+        const double *src = (tid < 64) ? p.px : (tid < 128 ? p.py : p.pz);
+        spos[tid] = src[64 * t + (tid & 63)];
+    }
+    // per-atom operands of the final steps: thread (component q = tid / 64 of atom i = tid % 64), tid < 192
+    double f_al = 0.0, f_es = 0.0, f_yu = 0.0;
+    if (tid < 192) {
+        const int k = 64 * t + lane;
+        f_al = p.alpha[k];
+        f_es = p.es[3 * k + w];
+        f_yu = p.y[3 * k + w];
+    }
+    // ---- neighbour tensor tile (t, t-1) into registers: wave w takes the sources j = w, w + 8, ...
+    double2 tn[8][3];
+    if (t >= 1) {
+        const double2 *src = p.Tnb + (size_t)t * kTnbDouble2 + lane;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int h = 0; h < 3; ++h) tn[k][h] = src[((w + 8 * k) * 3 + h) * 64];
+    }
+    __syncthreads();
+
+    // ---- sources s = 0 .. t-2 from the pair coefficients, as they are published
+    double ax = 0.0, ay = 0.0, az = 0.0;  // this wave's share of sum_s T(t,s) mu_s; alignment tracked by `fwd_done`
+    const int ns = t - 1;
+    bool last_forward = false;
+    {
+        double2 cA[8], cB[8];
+        double sxA = 0, syA = 0, szA = 0, sxB = 0, syB = 0, szB = 0;
+        auto load_tile = [&](int s, double2 (&c)[8], double &x, double &y, double &z) {
+            const double2 *tl = p.C + (size_t)(s * p.ntld + t) * tsz + (size_t)(8 * w) * 64 + lane;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) c[k] = tl[64 * k];
+            x = p.px[64 * s + lane];
+            y = p.py[64 * s + lane];
+            z = p.pz[64 * s + lane];
+        };
+        auto fetch_mu = [&](int s) {  // mu_s -> smu[q][atom]; false on a give-up
+            __syncthreads();          // the previous tile's readers are done with smu
+            if (tid < 192) {
+                bool ok = true;
+                const double v = poll_value(p.mu_new + 192 * (size_t)s + tid, p.flags, ok);
+                smu[(tid % 3) * 64 + tid / 3] = v;
+                if (!ok) s_ok = 0;
+            }
+            __syncthreads();
+            return s_ok != 0;
+        };
+        auto tile_product = [&](const double2 (&c)[8], double x, double y, double z, bool forward) {
+            const double mx = smu[lane], my = smu[64 + lane], mz = smu[128 + lane];
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const int k = forward ? kk : 7 - kk;
+                if (kk > 0) {  // the running sums follow their target atom to the neighbouring lane
+                    if (forward) {
+                        ax = wave_rotate_down(ax);
+                        ay = wave_rotate_down(ay);
+                        az = wave_rotate_down(az);
+                    } else {
+                        ax = wave_rotate_up(ax);
+                        ay = wave_rotate_up(ay);
+                        az = wave_rotate_up(az);
+                    }
+                }
+                const int jj = (lane + 8 * w + k) & 63;
+                double dx, dy, dz;
+                image_displacement<ORTHO>(p.bx, x - spos[jj], y - spos[64 + jj], z - spos[128 + jj], dx, dy, dz);
+                const double c3 = c[k].x, c5m = -3.0 * c[k].y;
+                const double wi = c5m * fma(dz, mz, fma(dy, my, dx * mx));
+                ax = fma(wi, dx, fma(c3, mx, ax));
+                ay = fma(wi, dy, fma(c3, my, ay));
+                az = fma(wi, dz, fma(c3, mz, az));
+            }
+        };
+        if (ns > 0) load_tile(0, cA, sxA, syA, szA);
+        for (int s = 0; s < ns; s += 2) {
+            if (s + 1 < ns) load_tile(s + 1, cB, sxB, syB, szB);
+            if (!fetch_mu(s)) return;
+            tile_product(cA, sxA, syA, szA, true);
+            last_forward = true;
+            if (s + 1 < ns) {
+                if (s + 2 < ns) load_tile(s + 2, cA, sxA, syA, szA);
+                if (!fetch_mu(s + 1)) return;
+                tile_product(cB, sxB, syB, szB, false);
+                last_forward = false;
+            }
+        }
+    }
+    // bring the sums back to "lane = target atom" through this wave's own scratch rows
+    {
+        const int jl = (lane + 8 * w + (last_forward ? 7 : 0)) & 63;
+        zred[(w * 3 + 0) * 64 + jl] = ax;
+        zred[(w * 3 + 1) * 64 + jl] = ay;
+        zred[(w * 3 + 2) * 64 + jl] = az;
+    }
+    __syncthreads();
+    ax = zred[(w * 3 + 0) * 64 + lane];
+    ay = zred[(w * 3 + 1) * 64 + lane];
+    az = zred[(w * 3 + 2) * 64 + lane];
+
+    // ---- the critical path: mu_{t-1} -> neighbour product -> v_t -> M_t v_t -> publish
+    if (t >= 1) {
+        __syncthreads();
+        if (tid < 192) {
+            bool ok = true;
+            const double v = poll_value(p.mu_new + 192 * (size_t)(t - 1) + tid, p.flags, ok);
+            smu[(tid % 3) * 64 + tid / 3] = v;
+            if (!ok) s_ok = 0;
+        }
+        __syncthreads();
+        if (!s_ok) return;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int j = w + 8 * k;
+            const double mx = smu[j], my = smu[64 + j], mz = smu[128 + j];  // wave-uniform: broadcast reads
+            ax = fma(tn[k][1].x, mz, fma(tn[k][0].y, my, fma(tn[k][0].x, mx, ax)));
+            ay = fma(tn[k][2].x, mz, fma(tn[k][1].y, my, fma(tn[k][0].y, mx, ay)));
+            az = fma(tn[k][2].y, mz, fma(tn[k][2].x, my, fma(tn[k][1].x, mx, az)));
+        }
+    }
+    __syncthreads();  // (everyone is done with smu and with the realignment reads of zred)
+    zred[(w * 3 + 0) * 64 + lane] = ax;
+    zred[(w * 3 + 1) * 64 + lane] = ay;
+    zred[(w * 3 + 2) * 64 + lane] = az;
+    __syncthreads();
+    double f_v = 0.0;
+    if (tid < 192) {
+        double sum = 0.0;
+#pragma unroll
+        for (int g = 0; g < kChainWaves; ++g) sum += zred[(g * 3 + w) * 64 + lane];
+        f_v = f_al * (f_es + (f_yu - sum));  // v_t = D (e + yU - sum_{s<t} T mu_s)
+        smu[w * 64 + lane] = f_v;
+    }
+    __syncthreads();
+    // M_t v_t: wave w takes the column groups g = w, w + 8, w + 16, w + 24 of the folded inverse
+    {
+        double a1x = 0.0, a1y = 0.0, a1z = 0.0, a2x = 0.0, a2y = 0.0, a2z = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int g = w + 8 * k;
+            const bool r1 = lane > g;                // role 1: (row lane, column g); role 2: (row 63-lane, column 62-g)
+            const int c1 = g, c2 = (g <= 30) ? 62 - g : g;
+            const double vx = r1 ? smu[c1] : smu[c2], vy = r1 ? smu[64 + c1] : smu[64 + c2],
+                         vz = r1 ? smu[128 + c1] : smu[128 + c2];
+            const double *m = sM + (size_t)(g * 9) * 64 + lane;
+            const double tx = fma(m[2 * 64], vz, fma(m[1 * 64], vy, m[0] * vx));
+            const double ty = fma(m[5 * 64], vz, fma(m[4 * 64], vy, m[3 * 64] * vx));
+            const double tz = fma(m[8 * 64], vz, fma(m[7 * 64], vy, m[6 * 64] * vx));
+            a1x += r1 ? tx : 0.0;
+            a1y += r1 ? ty : 0.0;
+            a1z += r1 ? tz : 0.0;
+            a2x += r1 ? 0.0 : tx;
+            a2y += r1 ? 0.0 : ty;
+            a2z += r1 ? 0.0 : tz;
+        }
+        // role-2 sums belong to row 63 - lane: mirror them across the wave
+        a1x += __shfl(a2x, 63 - lane, 64);
+        a1y += __shfl(a2y, 63 - lane, 64);
+        a1z += __shfl(a2z, 63 - lane, 64);
+        zred[(w * 3 + 0) * 64 + lane] = a1x;  // (zred was last read before the previous barrier)
+        zred[(w * 3 + 1) * 64 + lane] = a1y;
+        zred[(w * 3 + 2) * 64 + lane] = a1z;
+    }
+    __syncthreads();
+    if (tid < 192 && t != p.fault_block) {
+        double mu = f_v;
+#pragma unroll
+        for (int g = 0; g < kChainWaves; ++g) mu += zred[(g * 3 + w) * 64 + lane];
+        const int k = 64 * t + lane;
+        st_agent(p.mu_new + 3 * (size_t)k + w, mu);
+        // E_induced of the atom when it was updated (thole_iterative.c:44-46): mu = alpha (e + E_ind)
+        p.y[3 * k + w] = (f_al != 0.0) ? mu / f_al - f_es : 0.0;
+    }
+}
+
+}  // namespace mpmc

@@ -360,12 +360,14 @@ def test_incremental_updates_are_bit_identical_to_full_recomputation(pair_coeffi
         e.close()
 
 
-@pytest.mark.parametrize("persistent_gs", [2, 3, 1])
+@pytest.mark.parametrize("persistent_gs", [1, 0])
 def test_ranked_gauss_seidel_chain_keeps_its_view_incrementally(persistent_gs):
-    """Production flags (Wolf field, ranked Gauss-Seidel, Palmo, gamma 1.03): the ranked view's matrix stays
-    resident while the ranked walk does not change and only the moved atoms' rows / columns are rewritten;
-    the static-field and pair partials persist too.  A chain of moves must give bitwise the energies of an
-    engine that rebuilds everything every step, and track the oracle."""
+    """Production flags (Wolf field, ranked Gauss-Seidel, Palmo, gamma 1.03): the ranked view's data (pair
+    coefficients, cached block inverses, expanded sub-diagonal tiles -- or the expanded matrix with persistent_gs = 0,
+    the two-launches-per-block path) stay resident while the ranked walk does not change and only what involves a
+    moved atom is redone; the static-field and pair partials persist too.  Every cached unit is a pure function of
+    the current coordinates, so a chain of moves must give bitwise the energies of an engine that rebuilds everything
+    every step, and track the oracle."""
     s = synth.s_pol(640)
     p = dict(synth.FLAGS_POL_PRODUCTION)
     rng = np.random.default_rng(3)
@@ -375,7 +377,7 @@ def test_ranked_gauss_seidel_chain_keeps_its_view_incrementally(persistent_gs):
         e.load_system(s, p)
         e.set_option("incremental_amatrix", inc)
         e.set_option("incremental_pairs", inc)
-        e.set_option("persistent_gs", persistent_gs)  # 3: coefficient spine also for this small view, 1: never
+        e.set_option("persistent_gs", persistent_gs)  # 1: gs_chain_kernel (default), 0: gs_solve_block / gs_update
         engs.append(e)
     pos = s["pos"].copy()
     for step in range(10):
@@ -398,6 +400,51 @@ def test_ranked_gauss_seidel_chain_keeps_its_view_incrementally(persistent_gs):
             pos[first:first + 5] = new
     for e in engs:
         e.close()
+
+
+def test_gauss_seidel_chain_kernel_matches_the_literal_substitution():
+    """The chain kernel applies the cached inverse of each diagonal block instead of the reference's literal forward
+    substitution (thole_iterative.c:27-59); the two-launches-per-block path performs the literal substitution on the
+    expanded matrix.  Same dipoles to rounding, in atom order and in ranked order, orthorhombic and sheared cell."""
+    for shear in (False, True):
+        s = synth.s_pol(1024)
+        if shear:
+            L = s["basis"][0, 0]
+            s["basis"] = np.array([[L, 0, 0], [0.3 * L, 0.9 * L, 0], [-0.2 * L, 0.25 * L, 0.85 * L]])
+        for flags in (dict(polar_gs=1, polar_max_iter=3), dict(polar_gs_ranked=1, polar_max_iter=4, polar_palmo=1)):
+            p = dict(temperature=77.0, polarization=1, polar_damp=2.1304)
+            p.update(flags)
+            res = []
+            for persistent in (1, 0):
+                e = engine.Engine(1024)
+                e.load_system(s, p)
+                e.set_option("persistent_gs", persistent)
+                r = e.energy()
+                r.update(e.dipoles())
+                res.append(r)
+                e.close()
+            scale = np.abs(res[1]["mu"]).max()
+            assert np.abs(res[0]["mu"] - res[1]["mu"]).max() <= 1e-12 * scale
+            assert np.abs(res[0]["ef_induced"] - res[1]["ef_induced"]).max() <= 1e-11 * np.abs(res[1]["ef_induced"]).max()
+            assert rel(res[0]["polarization_energy"], res[1]["polarization_energy"]) < 1e-12
+
+
+def test_gauss_seidel_hand_off_timeout_is_sticky_and_reported():
+    """A hand-off that never arrives in sweep 1 of 4 must surface as an error of energy() -- not be erased by the
+    arming step of the later sweeps, and not come back as a non-finite energy the host would take for a rejected
+    move (test hook: option gs_fault_sweep makes one block's workgroup skip its publication)."""
+    s = synth.s_pol(640)
+    p = dict(temperature=77.0, polarization=1, polar_damp=2.1304, polar_gs=1, polar_max_iter=4)
+    e = engine.Engine(640)
+    e.load_system(s, p)
+    good = e.energy()
+    e.set_option("gs_fault_sweep", 1)
+    with pytest.raises(engine.EngineError, match="hand-off"):
+        e.energy()
+    e.set_option("gs_fault_sweep", 0)
+    again = e.energy()  # the context recovers: everything is re-armed per sweep / per call
+    assert again["energy"] == good["energy"]
+    e.close()
 
 
 def test_insert_and_remove_molecule_through_the_abi():
