@@ -100,6 +100,8 @@ typedef struct mpmc_hip_timings {
     int graph_steps;      /* energy() calls replayed as a HIP graph so far (option "step_graph") */
     float event_pair_ms;  /* calibration: summed elapsed time of EMPTY event pairs (two records, nothing  */
     int event_pair_count; /* between): what an event pair adds to the kernel it brackets               */
+    int spec_rank_redos;  /* polar_gs_ranked: calls repeated because the ranked walk assumed at enqueue time was
+                           * not the one the new ranking metric gives (cumulative)              */
 } mpmc_hip_timings;
 
 const char *mpmc_hip_last_error(void);

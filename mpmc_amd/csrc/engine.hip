@@ -92,7 +92,8 @@ enum ResSlot {
     R_UPOL = 7,
     R_RRMS = 8,
     R_GS_ERR = 9,  // bit 0 / 1: the persistent Gauss-Seidel kernel of view 0 / 1 gave up on a hand-off
-    R_RMIN = 9,
+    R_RMIN = 10,
+    R_RANKCHG = 11,  // speculative ranked call: 1 = the ranking metric differs from the one the ranked view was built for
     R_COUNT = 16
 };
 
@@ -248,6 +249,18 @@ struct mpmc_hip_ctx {
     unsigned long long *h_err = nullptr;  // pinned, 1 word
     unsigned *h_gserr = nullptr;          // pinned: error words of the persistent Gauss-Seidel kernel (2 views)
     bool gs_used[2] = {false, false};
+    // polar_gs_ranked without a host round trip: the ranked view (1) is kept for the walk of the previous call and
+    // the whole evaluation is enqueued on that assumption; the device compares the new ranking metric with the one
+    // that walk was sorted from (d_rank_used) and energy_end() repeats the call the slow way if they differ
+    double *d_rank_used = nullptr;
+    unsigned int *d_rankcnt = nullptr;    // neighbour counters of the ranking metric
+    std::vector<int> perm_sorted;         // the walk d_rank_used gives (all atoms, as ranked_array)
+    bool rank_used_valid = false;
+    bool force_host_rank = false;         // this call: no speculation
+    bool call_spec_rank = false;          // the call in flight was enqueued speculatively
+    int opt_spec_rank = 1;
+    unsigned long long spec_redos = 0;
+    hipEvent_t ev_rank = nullptr;
     double *h_rank = nullptr;             // pinned, max_npad
     int *h_perm = nullptr;                // pinned, max_npad
     std::vector<int> perm;                // final sweep order (all atoms, as ranked_array)
@@ -435,6 +448,8 @@ extern "C" int mpmc_hip_set_option(mpmc_hip_ctx *c, const char *name, int value)
         c->opt_sym_mode = value;
     else if (!strcmp(name, "persistent_gs"))
         c->opt_persistent_gs = value;
+    else if (!strcmp(name, "speculative_ranking"))
+        c->opt_spec_rank = value;  // 0: polar_gs_ranked asks the host for the sweep order in every call (A/B)
     else if (!strcmp(name, "gs_fault_sweep"))
         c->opt_gs_fault_sweep = value;  // test hook: in Gauss-Seidel sweep number `value` (1-based) block 1 never publishes
     else if (!strcmp(name, "pair_coefficients")) {
@@ -496,6 +511,7 @@ extern "C" int mpmc_hip_create(mpmc_hip_ctx **out, int device, int max_atoms) {
     HIPCHK(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_least));
     HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_rank, hipEventDisableTiming));
 #define DALLOC(ptr, count, type) HIPCHK(hipMalloc((void **)&(ptr), (count) * sizeof(type)))
     DALLOC(c->d_x, np, double);
     DALLOC(c->d_y, np, double);
@@ -513,6 +529,8 @@ extern "C" int mpmc_hip_create(mpmc_hip_ctx **out, int device, int max_atoms) {
     DALLOC(c->d_efchg, 3 * np, double);
     DALLOC(c->d_tmp3, 3 * np, double);
     DALLOC(c->d_rank, np, double);
+    DALLOC(c->d_rank_used, np, double);
+    DALLOC(c->d_rankcnt, np, unsigned int);
     DALLOC(c->d_errmax, 256, unsigned long long);
     for (SweepView &v : c->view) {
         v.cap = (int)np;
@@ -583,7 +601,7 @@ extern "C" void mpmc_hip_destroy(mpmc_hip_ctx *c) {
     if (c->stream2) hipStreamSynchronize(c->stream2);
     void *dptrs[] = {c->d_x,   c->d_y,     c->d_z,     c->d_q,    c->d_alpha, c->d_eps,      c->d_sig,
                      c->d_molmass, c->d_mol, c->d_flags, c->d_es, c->d_mu,    c->d_efind,    c->d_efchg,
-                     c->d_tmp3, c->d_rank, c->d_errmax, c->d_pairpart, c->d_fieldpart, c->d_kvec,
+                     c->d_tmp3, c->d_rank, c->d_rank_used, c->d_rankcnt, c->d_errmax, c->d_pairpart, c->d_fieldpart, c->d_kvec,
                      c->d_res,  c->d_kvecf, c->d_sf, c->d_lrcpart, c->d_rankpart, c->d_sfpart, c->d_recipsum};
     for (void *p : dptrs)
         if (p) hipFree(p);
@@ -597,6 +615,7 @@ extern "C" void mpmc_hip_destroy(mpmc_hip_ctx *c) {
     if (c->stream2) hipStreamDestroy(c->stream2);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
+    if (c->ev_rank) hipEventDestroy(c->ev_rank);
     if (c->h_res) hipHostFree(c->h_res);
     if (c->h_err) hipHostFree(c->h_err);
     if (c->h_gserr) hipHostFree(c->h_gserr);
@@ -780,6 +799,7 @@ extern "C" int mpmc_hip_upload(mpmc_hip_ctx *c, int n, const double *x, const do
     c->view[0].A_valid = c->view[1].A_valid = false;
     c->view[0].C_valid = c->view[1].C_valid = false;
     c->view[0].pos_valid = c->view[1].pos_valid = false;
+    c->rank_used_valid = false;
     ++c->config_rev;
     if (v0.nv > 0) HIPCHK(hipMemcpy(v0.d_idx, v0.h_idx.data(), v0.nv * sizeof(int), hipMemcpyHostToDevice));
     return 0;
@@ -1624,11 +1644,9 @@ extern "C" int mpmc_hip_energy_end(mpmc_hip_ctx *c, mpmc_hip_result *out) {
     c->in_flight = false;
     memset(out, 0, sizeof(*out));
     const mpmc_hip_params &P = c->par;
-    const bool do_polar = c->call_polar, timed_call = c->call_timed;
-    const int polar_iterations = c->call_iterations, iter_success = c->call_iter_success;
     timespec ts1, ts2;
     clock_gettime(CLOCK_MONOTONIC, &ts1);
-    {
+    auto wait_record = [&]() -> int {
         // spin on the sequence number the publish kernel writes last; fall back to a stream sync if it
         // does not show up (also surfaces launch errors)
         volatile double *seq = c->h_res + R_COUNT;
@@ -1643,9 +1661,30 @@ extern "C" int mpmc_hip_energy_end(mpmc_hip_ctx *c, mpmc_hip_result *out) {
             __builtin_ia32_pause();
         }
         if (!seen) HIPCHK(hipStreamSynchronize(c->stream));
+        return 0;
+    };
+    if (wait_record()) return -1;
+    if (c->call_spec_rank && c->h_res[R_GS_ERR] == 0.0 && c->h_res[R_RANKCHG] != 0.0) {
+        // polar_gs_ranked, speculative call: the ranking metric is not the one the resident ranked view was built
+        // for (molecules came within 1.5 r_min of each other, or moved apart again).  Nothing that call produced is
+        // used; the evaluation is repeated with the host sorting the new metric (which rebuilds the ranked view).
+        // Everything else resident -- pair / field partials, view 0 -- is already up to date and is not redone.
+        ++c->spec_redos;
+        c->force_host_rank = true;
+        ++c->energy_calls;
+        c->ev_next = 0;
+        c->recs.clear();
+        c->gs_used[0] = c->gs_used[1] = false;
+        collect_dirty_blocks(c);
+        const int rc = enqueue_direct(c);
+        c->force_host_rank = false;
+        if (rc) return -1;
+        if (wait_record()) return -1;
     }
     clock_gettime(CLOCK_MONOTONIC, &ts2);
     c->host_wait_s += (ts2.tv_sec - ts1.tv_sec) + 1e-9 * (ts2.tv_nsec - ts1.tv_nsec);
+    const bool do_polar = c->call_polar, timed_call = c->call_timed;
+    const int polar_iterations = c->call_iterations, iter_success = c->call_iter_success;
     const int gs_err = (int)c->h_res[R_GS_ERR];
     c->h_gserr[0] = gs_err & 1;
     c->h_gserr[1] = (gs_err >> 1) & 1;
@@ -1743,6 +1782,7 @@ extern "C" int mpmc_hip_get_timings(mpmc_hip_ctx *c, mpmc_hip_timings *t) {
     if (!c || !t) return fail("MPMC_HIP: get_timings: null argument");
     memset(t, 0, sizeof(*t));
     t->graph_steps = (int)c->graph_launches;
+    t->spec_rank_redos = (int)c->spec_redos;
     if (!c->timed) return 0;
     HIPCHK(hipSetDevice(c->device));
     float acc[T_NCLASS] = {0};

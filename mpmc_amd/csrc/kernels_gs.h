@@ -292,8 +292,13 @@ __global__ __launch_bounds__(64) void rank_rmin_kernel(DevAtoms a, DevBox bx, do
     if (lane == 0) out[0] = (rmin2 < kMAXVALUE) ? sqrt(rmin2) : kMAXVALUE;
 }
 
+// (also clears `nzero` words at `zero` -- the neighbour counters of rank_count_kernel -- and one double, instead
+// of memset launches)
 __global__ __launch_bounds__(256) void reduce_min_kernel(const double *__restrict__ in, int count,
-                                                          double *__restrict__ out) {
+                                                          double *__restrict__ out, unsigned int *__restrict__ zero,
+                                                          int nzero, double *__restrict__ zero_word) {
+    for (int r = threadIdx.x; r < nzero; r += blockDim.x) zero[r] = 0u;
+    if (zero_word && threadIdx.x == 0) *zero_word = 0.0;
     double m = kMAXVALUE;
     for (int r = threadIdx.x; r < count; r += blockDim.x) m = fmin(m, in[r]);
     m = wave_min(m);
@@ -334,10 +339,41 @@ __global__ __launch_bounds__(64) void rank_count_kernel(DevAtoms a, const double
     if (n) atomicAdd(cnt + i, n);
 }
 
+// Also compares the new metric with the one the ranked view's walk was sorted from (`used`, may be null):
+// *changed = 1.0 as soon as one atom's rank differs.  The stable descending sort of update_ranking()
+// (thole_iterative.c:143-164) is a pure function of the metric, so an unchanged metric means an unchanged walk --
+// which is what lets the engine keep the ranked view resident and enqueue a whole call without asking the host
+// (`changed` is zeroed by the caller's reduce_min launch, earlier in the same stream).
 __global__ __launch_bounds__(256) void count_to_rank_kernel(int npad, const unsigned int *__restrict__ cnt,
-                                                             double *__restrict__ rank) {
+                                                             double *__restrict__ rank, int n,
+                                                             const double *__restrict__ used,
+                                                             double *__restrict__ changed) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < npad) rank[i] = (double)cnt[i];
+    if (i >= npad) return;
+    const double r = (double)cnt[i];
+    rank[i] = r;
+    if (used && i < n && used[i] != r) *changed = 1.0;  // (racing writers all store the same value)
+}
+
+// The switch from the atom-order view (0) to the ranked view (1) after the first sweep of polar_gs_ranked: view 1's
+// static field and current dipoles are those of the same atoms in view 0; its per-call scratch is cleared.  One
+// launch instead of a field reduction, two scatters / gathers and four fills.
+__global__ __launch_bounds__(256) void switch_view_kernel(int nv, int nvpad, const int *__restrict__ idx1,
+                                                           const int *__restrict__ slot0,
+                                                           const double *__restrict__ es0,
+                                                           const double *__restrict__ mu0, double *__restrict__ es1,
+                                                           double *__restrict__ mu1, double *__restrict__ efchg1,
+                                                           double *__restrict__ rrms1) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nvpad) return;
+    const int s = (k < nv) ? slot0[idx1[k]] : -1;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        es1[3 * k + p] = (s >= 0) ? es0[3 * s + p] : 0.0;
+        mu1[3 * k + p] = (s >= 0) ? mu0[3 * s + p] : 0.0;
+        efchg1[3 * k + p] = 0.0;
+    }
+    rrms1[k] = 0.0;
 }
 
 }  // namespace mpmc

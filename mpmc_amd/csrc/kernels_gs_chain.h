@@ -74,6 +74,9 @@ struct GsChain {
     int fault_block;   // test hook: the workgroup of this block never publishes (-1 = off)
 };
 
+// offset of column / row j in a packed strict triangle of a 64-atom block: j 63 - j (j - 1) / 2
+__device__ __forceinline__ int gs_row_offset(int j) { return j * (kGsBlock - 1) - j * (j - 1) / 2; }
+
 __device__ __forceinline__ void st_agent(double *p, double v) {
     __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v),
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -142,29 +145,25 @@ __global__ __launch_bounds__(256) void gs_neighbor_tensor_kernel(const double2 *
 
 // ---------------------------------------------------------------------------------------------
 // M_t = (I + D L)^-1 of block t = blk[blockIdx.y] (or blockIdx.y with nsel = 0): forward substitution on the
-// identity.  Columns are independent, so a block is spread over 16 workgroups (blockIdx.x = group of 4 column
-// atoms) of 12 waves (wave = one scalar column): lane b holds x_b, the column's 3 entries in atom b's rows; step a
-// forms x_a = -alpha_a sum_{b<a} T_ab x_b with a 64-lane reduction.  The block's tensors are expanded once into
-// LDS from the diagonal coefficient tile (packed lower triangle, 6 doubles per pair).
-// grid = (16, nsel or nb); block = 768; dynamic LDS = kInverseLds.
+// identity, right-looking.  Columns are independent, so a block is spread over 48 workgroups of 4 waves (one wave
+// per SIMD, one scalar column per wave): lane a accumulates r_a = sum_{b<a} T_ab x_b; at step b the finished
+// x_b = -alpha_b r_b leaves lane b through SGPRs (v_readlane, no LDS crossbar, no reduction) and every lane a > b
+// adds T_ab x_b.  The block's tensors are expanded once into LDS from the diagonal coefficient tile (packed by
+// column: rows a > b of column b are contiguous, 6 doubles per pair).
+// grid = (48, nsel or nb); block = 256; dynamic LDS = kInverseLds.
 // ---------------------------------------------------------------------------------------------
 constexpr int kInverseLds = (kGsPairs * 6 + 4 * 64) * 8;
-
-__device__ __forceinline__ double wave_sum_bcast(double v) {  // every lane gets the total, fixed order
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
+constexpr int kInverseGroups = 48;
 
 template <int ORTHO>
-__global__ __launch_bounds__(768) void gs_block_inverse_kernel(const double2 *__restrict__ C, int ntld,
+__global__ __launch_bounds__(256) void gs_block_inverse_kernel(const double2 *__restrict__ C, int ntld,
                                                                 const double *__restrict__ px,
                                                                 const double *__restrict__ py,
                                                                 const double *__restrict__ pz,
                                                                 const double *__restrict__ alpha, DevBox bx, BlockList sel,
                                                                 double *__restrict__ Minv) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *T6 = lds;                  // row a (1..63): offset 6 * a (a - 1) / 2, then [e][b], b < a
+    double *T6 = lds;                  // column b (0..62): offset 6 (63 b - b (b - 1) / 2), then [e][a - b - 1], a > b
     double *sx = lds + kGsPairs * 6;   // [64] x, y, z, alpha of the block
     double *sy = sx + 64, *sz = sy + 64, *sal = sz + 64;
     const int t = (sel.n > 0) ? sel.blk[blockIdx.y] : (int)blockIdx.y;
@@ -178,54 +177,55 @@ __global__ __launch_bounds__(768) void gs_block_inverse_kernel(const double2 *__
     __syncthreads();
     // expand the strictly lower triangle: pair (a, b), a > b, is element (l = b, s = a - b) of the diagonal tile
     const double2 *tile = C + (size_t)(t * ntld + t) * (kCoefTile * kCoefTile);
-    for (int s = 1 + w; s < 64; s += 12) {
+    for (int s = 1 + w; s < 64; s += 4) {
         const int b = lane, a = lane + s;
         if (a < 64) {
             const double2 c = tile[s * 64 + b];
             double dx, dy, dz;
             image_displacement<ORTHO>(bx, sx[b] - sx[a], sy[b] - sy[a], sz[b] - sz[a], dx, dy, dz);
             const double c3 = c.x, c5 = c.y;
-            double *row = T6 + 3 * a * (a - 1);  // 6 * a (a - 1) / 2
-            row[0 * a + b] = -3.0 * dx * dx * c5 + c3;
-            row[1 * a + b] = -3.0 * dx * dy * c5;
-            row[2 * a + b] = -3.0 * dx * dz * c5;
-            row[3 * a + b] = -3.0 * dy * dy * c5 + c3;
-            row[4 * a + b] = -3.0 * dy * dz * c5;
-            row[5 * a + b] = -3.0 * dz * dz * c5 + c3;
+            const int wd = 63 - b;
+            double *col = T6 + 6 * gs_row_offset(b) + (a - b - 1);
+            col[0 * wd] = -3.0 * dx * dx * c5 + c3;
+            col[1 * wd] = -3.0 * dx * dy * c5;
+            col[2 * wd] = -3.0 * dx * dz * c5;
+            col[3 * wd] = -3.0 * dy * dy * c5 + c3;
+            col[4 * wd] = -3.0 * dy * dz * c5;
+            col[5 * wd] = -3.0 * dz * dz * c5 + c3;
         }
     }
     __syncthreads();
-    const int c = 4 * blockIdx.x + w / 3, q = w % 3;  // this wave's column: atom c, component q
-    double x0 = 0.0, x1 = 0.0, x2 = 0.0;
-    if (lane == c) {
-        x0 = (q == 0) ? 1.0 : 0.0;
-        x1 = (q == 1) ? 1.0 : 0.0;
-        x2 = (q == 2) ? 1.0 : 0.0;
-    }
-    for (int a = c + 1; a < 64; ++a) {
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-        if (lane >= c && lane < a) {
-            const double *row = T6 + 3 * a * (a - 1) + lane;
-            const double xx = row[0], xy = row[a], xz = row[2 * a], yy = row[3 * a], yz = row[4 * a], zz = row[5 * a];
-            s0 = fma(xz, x2, fma(xy, x1, xx * x0));
-            s1 = fma(yz, x2, fma(yy, x1, xy * x0));
-            s2 = fma(zz, x2, fma(yz, x1, xz * x0));
+    const int colidx = 4 * blockIdx.x + w;   // this wave's scalar column of M: atom c, component q
+    const int c = colidx / 3, q = colidx % 3;
+    const double al = sal[lane];
+    double r0 = 0.0, r1 = 0.0, r2 = 0.0;     // lane a: sum_{c <= b < a} T_ab x_b
+    for (int b = c; b < 63; ++b) {
+        // x_b: the unit vector for b == c, else -alpha_b r_b of lane b (wave-uniform after the broadcast)
+        double x0, x1, x2;
+        if (b == c) {
+            x0 = (q == 0) ? 1.0 : 0.0;
+            x1 = (q == 1) ? 1.0 : 0.0;
+            x2 = (q == 2) ? 1.0 : 0.0;
+        } else {
+            const double nb_al = -sal[b];
+            x0 = nb_al * readlane_f64(r0, b);
+            x1 = nb_al * readlane_f64(r1, b);
+            x2 = nb_al * readlane_f64(r2, b);
         }
-        s0 = wave_sum_bcast(s0);
-        s1 = wave_sum_bcast(s1);
-        s2 = wave_sum_bcast(s2);
-        if (lane == a) {
-            const double al = sal[a];
-            x0 = -al * s0;
-            x1 = -al * s1;
-            x2 = -al * s2;
+        if (lane > b) {
+            const int wd = 63 - b;
+            const double *col = T6 + 6 * gs_row_offset(b) + (lane - b - 1);
+            const double xx = col[0], xy = col[wd], xz = col[2 * wd], yy = col[3 * wd], yz = col[4 * wd], zz = col[5 * wd];
+            r0 = fma(xz, x2, fma(xy, x1, fma(xx, x0, r0)));
+            r1 = fma(yz, x2, fma(yy, x1, fma(xy, x0, r1)));
+            r2 = fma(zz, x2, fma(yz, x1, fma(xz, x0, r2)));
         }
     }
     if (lane > c) {
         double *out = Minv + (size_t)t * kMinvDoubles;
-        out[minv_index(lane, c, 0 + q)] = x0;
-        out[minv_index(lane, c, 3 + q)] = x1;
-        out[minv_index(lane, c, 6 + q)] = x2;
+        out[minv_index(lane, c, 0 + q)] = -al * r0;
+        out[minv_index(lane, c, 3 + q)] = -al * r1;
+        out[minv_index(lane, c, 6 + q)] = -al * r2;
     }
 }
 

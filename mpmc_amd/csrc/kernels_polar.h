@@ -664,10 +664,18 @@ __global__ __launch_bounds__(64 * kFieldGroups) void init_view_kernel(int nv, in
                                                                        double *__restrict__ ef_induced,
                                                                        double *__restrict__ ef_change,
                                                                        double *__restrict__ rrms,
-                                                                       unsigned long long *__restrict__ errmax) {
+                                                                       unsigned long long *__restrict__ errmax,
+                                                                       unsigned *__restrict__ gsflags0,
+                                                                       unsigned *__restrict__ gsflags1) {
     __shared__ double red[kFieldGroups][3][kWave];
     const int k = blockIdx.x * kWave + (threadIdx.x & 63);
     if (blockIdx.x == 0 && threadIdx.x < 256) errmax[threadIdx.x] = 0ull;
+    // the Gauss-Seidel chain's control words (ticket, STICKY error word, breadcrumbs) of both views: cleared once
+    // per energy() here, never by a sweep
+    if (blockIdx.x == 0 && threadIdx.x < 8) {
+        if (gsflags0) gsflags0[threadIdx.x] = 0u;
+        if (gsflags1) gsflags1[threadIdx.x] = 0u;
+    }
     const int src = (k < nv) ? idx[k] : -1;
     double e[3];
     reduce_field_partials(part, nslots, npad, src, red, e);

@@ -92,6 +92,7 @@ class Timings(C.Structure):
         ("graph_steps", C.c_int),
         ("event_pair_ms", C.c_float),
         ("event_pair_count", C.c_int),
+        ("spec_rank_redos", C.c_int),
     ]
 
 
@@ -270,6 +271,11 @@ class Engine:
         A = np.zeros((3 * self.n, 3 * self.n))
         _chk(self.lib.mpmc_hip_download_amatrix(self.ctx, A.ctypes.data))
         return A
+
+    def timings(self):
+        t = Timings()
+        _chk(self.lib.mpmc_hip_get_timings(self.ctx, C.byref(t)))
+        return {f: getattr(t, f) for f, _ in Timings._fields_}
 
     def ranking(self):
         rank = np.zeros(self.n)

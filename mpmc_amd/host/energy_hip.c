@@ -404,6 +404,7 @@ double energy_end(system_t *system) {
             s->other_ms += t.other_ms; s->total_ms += t.total_ms;
             s->sweep_count += t.sweep_count; s->amatrix_count += t.amatrix_count;
             s->event_pair_ms += t.event_pair_ms; s->event_pair_count += t.event_pair_count;
+            s->spec_rank_redos = t.spec_rank_redos; /* cumulative in the engine */
         }
     }
     observables_t *o = system->observables;

@@ -429,6 +429,54 @@ def test_gauss_seidel_chain_kernel_matches_the_literal_substitution():
             assert rel(res[0]["polarization_energy"], res[1]["polarization_energy"]) < 1e-12
 
 
+def test_ranked_walk_is_speculated_and_repeated_when_the_metric_changes():
+    """polar_gs_ranked without a host round trip: the ranked view of the previous call is assumed to be the right
+    walk, the device compares the ranking metric, and a call whose metric changed is repeated with the host sorting
+    it.  A chain in which one molecule is pushed onto another (two G sites 0.3 A apart: inside 1.5 r_min, so their
+    rank_metric and the walk change) and pulled back must equal, bit for bit, the chain of an engine that asks the
+    host in every call -- energies, rank_metric and sweep order -- and follow the oracle."""
+    s = synth.s_pol(640)
+    p = dict(synth.FLAGS_POL_PRODUCTION)
+    engs = []
+    for spec in (1, 0):
+        e = engine.Engine(640)
+        e.load_system(s, p)
+        e.set_option("speculative_ranking", spec)
+        engs.append(e)
+    pos = s["pos"].copy()
+    target = pos[5 * 7:5 * 7 + 5].copy()  # molecule 7
+    moves = [(3, pos[15:20] + np.array([0.2, -0.1, 0.1])),            # ordinary displacement
+             (20, target + np.array([0.3, 0.0, 0.0])),                # molecule 20 lands on molecule 7: walk changes
+             (31, pos[5 * 31:5 * 31 + 5] + np.array([-0.1, 0.2, 0.0])),  # ordinary, with the changed walk resident
+             (20, pos[100:105]),                                      # pulled back: walk changes again
+             (40, pos[200:205] + np.array([0.1, 0.1, -0.2]))]
+    orders = []
+    for mol, new in moves:
+        first = 5 * mol
+        got = []
+        for e in engs:
+            e.update_atoms(first, new)
+            r = e.energy()
+            r["rank"], r["order"] = e.ranking()
+            got.append(r)
+        pos[first:first + 5] = new
+        for key in ("energy", "polarization_energy", "rd_energy", "coulombic_energy"):
+            assert got[0][key] == got[1][key], (mol, key)
+        assert np.array_equal(got[0]["rank"], got[1]["rank"]) and np.array_equal(got[0]["order"], got[1]["order"])
+        s2 = dict(s)
+        s2["pos"] = pos.copy()
+        want = oracle.energy(s2, p, want_vectors=True)
+        check_energies(got[0], want)
+        assert np.array_equal(got[0]["order"], want["ranked_array"])
+        orders.append(got[0]["order"].copy())
+    assert not np.array_equal(orders[0], orders[1]) and np.array_equal(orders[1], orders[2])
+    assert not np.array_equal(orders[2], orders[3]) and np.array_equal(orders[0], orders[4])
+    redo = [e.timings()["spec_rank_redos"] for e in engs]
+    assert redo == [2, 0]  # exactly the two calls whose metric changed were repeated; the host-sorted engine never
+    for e in engs:
+        e.close()
+
+
 def test_gauss_seidel_hand_off_timeout_is_sticky_and_reported():
     """A hand-off that never arrives in sweep 1 of 4 must surface as an error of energy() -- not be erased by the
     arming step of the later sweeps, and not come back as a non-finite energy the host would take for a rejected
