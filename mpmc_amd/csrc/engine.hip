@@ -119,6 +119,7 @@ struct SweepView {
     unsigned long long ranked_call = 0;  // view 1: the energy() call that last walked (and so maintained) it
     int *d_slot = nullptr;  // device copy of slot_of_atom (padded with -1)
     std::vector<int> slot_of_atom;  // atom index -> view slot, -1 if not in the view
+    double *mupub = nullptr;  // Gauss-Seidel chain: the published dipoles of a sweep, planar per block (hand-off buffer)
     double *es = nullptr, *mu0 = nullptr, *mu1 = nullptr, *munew = nullptr, *y = nullptr, *efind = nullptr,
            *efchg = nullptr, *rrms = nullptr;
     unsigned *gsflags = nullptr; // [8] gs_chain_kernel: ticket counter, sticky error word, breadcrumbs
@@ -545,6 +546,7 @@ extern "C" int mpmc_hip_create(mpmc_hip_ctx **out, int device, int max_atoms) {
         DALLOC(v.mu0, 3 * np, double);
         DALLOC(v.mu1, 3 * np, double);
         DALLOC(v.munew, 3 * np, double);
+        DALLOC(v.mupub, 3 * np, double);
         DALLOC(v.y, 3 * np, double);
         DALLOC(v.efind, 3 * np, double);
         DALLOC(v.efchg, 3 * np, double);
@@ -606,7 +608,7 @@ extern "C" void mpmc_hip_destroy(mpmc_hip_ctx *c) {
     for (void *p : dptrs)
         if (p) hipFree(p);
     for (SweepView &v : c->view) {
-        void *vp[] = {v.Srow, v.Minv, v.Tnb, v.gsflags, v.d_idx, v.d_slot, v.px, v.py, v.pz, v.palpha, v.pflags, v.A,    v.C, v.energy_part, v.es,
+        void *vp[] = {v.Srow, v.Minv, v.Tnb, v.mupub, v.gsflags, v.d_idx, v.d_slot, v.px, v.py, v.pz, v.palpha, v.pflags, v.A,    v.C, v.energy_part, v.es,
                       v.mu0,   v.mu1, v.munew, v.y, v.efind, v.efchg, v.rrms};
         for (void *p : vp)
             if (p) hipFree(p);
@@ -1696,7 +1698,7 @@ extern "C" int mpmc_hip_energy_end(mpmc_hip_ctx *c, mpmc_hip_result *out) {
         hipMemcpy(dbg, gv.gsflags, sizeof(dbg), hipMemcpyDeviceToHost);  // (the allocation is exactly 8 words)
         return fail("MPMC_HIP: persistent Gauss-Seidel kernel gave up waiting on a hand-off (spin limit) in view %d: "
                     "workgroup %u thread %u addr-lo 0x%x; mu_new-lo 0x%x",
-                    c->h_gserr[1] ? 1 : 0, dbg[2], dbg[3], dbg[4], (unsigned)((unsigned long long)gv.munew & 0xffffffffu));
+                    c->h_gserr[1] ? 1 : 0, dbg[2], dbg[3], dbg[4], (unsigned)((unsigned long long)gv.mupub & 0xffffffffu));
     }
     HIPCHK(hipGetLastError());
     c->timed = timed_call;

@@ -183,9 +183,10 @@ __global__ __launch_bounds__(256) void gs_update_kernel(const double *__restrict
 __global__ __launch_bounds__(256) void gs_finish_kernel(int npad, const double *__restrict__ alpha,
                                                          const int *__restrict__ flags,
                                                          const double *__restrict__ mu_old,
-                                                         const double *__restrict__ mu_new,
+                                                         const double *__restrict__ mu_new, int planar,
                                                          const double *__restrict__ y, double w_new, double w_old,
                                                          int want_rrms, int err_slot, double *__restrict__ mu_out,
+                                                         double *__restrict__ mu_new_lin,
                                                          double *__restrict__ ef_induced,
                                                          double *__restrict__ rrms,
                                                          unsigned long long *__restrict__ errmax) {
@@ -195,8 +196,11 @@ __global__ __launch_bounds__(256) void gs_finish_kernel(int npad, const double *
     double d2 = 0.0, n2 = 0.0, emax = 0.0;
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
-        const double nw = polar ? mu_new[3 * i + p] : 0.0;
+        // the chain kernel publishes a block as [component][atom] (kernels_gs_chain.h); `mu_new_lin` receives the
+        // usual [atom][component] copy the Palmo contraction reads
+        const double nw = polar ? mu_new[planar ? 192 * (i >> 6) + 64 * p + (i & 63) : 3 * i + p] : 0.0;
         const double old = mu_old[3 * i + p];
+        if (mu_new_lin) mu_new_lin[3 * i + p] = nw;
         ef_induced[3 * i + p] = polar ? y[3 * i + p] : 0.0;
         mu_out[3 * i + p] = polar ? (w_new * nw + w_old * old) : 0.0;
         const double d = nw - old;

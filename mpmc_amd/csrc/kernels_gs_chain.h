@@ -68,7 +68,9 @@ struct GsChain {
     const double *Minv;
     const double2 *Tnb;
     double *y;         // in: upper-triangle part (pair_upper_finish_kernel); out: E_induced at update time
-    double *mu_new;    // out; pre-filled with kGsSentinel
+    double *mu_new;    // out, PLANAR per block: mu_new[192 t + 64 q + i] = component q of atom i of block t (so that a
+                       // block is published with 16-byte stores and polled with coalesced loads); pre-filled with
+                       // kGsSentinel
     unsigned *flags;   // [0] ticket counter (zeroed per sweep), [1] sticky error word, [2..4] breadcrumbs
     DevBox bx;
     int fault_block;   // test hook: the workgroup of this block never publishes (-1 = off)
@@ -77,19 +79,49 @@ struct GsChain {
 // offset of column / row j in a packed strict triangle of a 64-atom block: j 63 - j (j - 1) / 2
 __device__ __forceinline__ int gs_row_offset(int j) { return j * (kGsBlock - 1) - j * (j - 1) / 2; }
 
-__device__ __forceinline__ void st_agent(double *p, double v) {
-    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v),
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// Publication of two adjacent doubles with ONE 16-byte write-through (sc1) store.  Every double is its own flag
+// (valid <=> different from the sentinel) and each 8-byte half is single-copy atomic, so a consumer that sees the
+// two halves at different times is still correct; wide stores matter because an sc1 store leaves the CU as its own
+// fabric write (MI355X_MICROARCH.md: a dwordx2 costs 2.7x a dwordx4 per byte) and a block publishes 192 doubles on
+// the critical path of the sweep.
+__device__ __forceinline__ void st_agent16(double *p, double a, double b) {
+    typedef double __attribute__((ext_vector_type(2))) d2_t;
+    const d2_t v = {a, b};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
 }
 
-// poll one double until it differs from the sentinel (agent-scope loads bypass the never-refreshed L1)
+__device__ __forceinline__ unsigned long long ld_agent_u64(const unsigned long long *q) {
+    return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Poll one double until it differs from the sentinel (agent-scope loads bypass the never-refreshed L1).
+// URGENT: three loads are kept in flight, so the value is seen within one issue interval (~0.1 us) of its arrival
+// instead of one load round trip (~0.7 us): for the hand-offs on the sweep's critical path.  Otherwise one load at a
+// time with a longer sleep (a workgroup far behind the front only has to notice within several block times).
+template <bool URGENT>
 __device__ __forceinline__ double poll_value(const double *p, unsigned *flags, bool &ok) {
     const unsigned long long *q = reinterpret_cast<const unsigned long long *>(p);
-    for (unsigned it = 0; it < kGsSpinLimit; ++it) {
-        const unsigned long long v = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (v != kGsSentinel) return __longlong_as_double((long long)v);
-        if ((it & 255u) == 255u && __hip_atomic_load(flags + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+    if (URGENT) {
+        unsigned long long v0 = ld_agent_u64(q);
         __builtin_amdgcn_s_sleep(1);
+        unsigned long long v1 = ld_agent_u64(q);
+        __builtin_amdgcn_s_sleep(1);
+        unsigned long long v2 = ld_agent_u64(q);
+        for (unsigned it = 0; it < 4 * kGsSpinLimit; ++it) {
+            if (v0 != kGsSentinel) return __longlong_as_double((long long)v0);
+            v0 = v1;
+            v1 = v2;
+            if ((it & 1023u) == 1023u && __hip_atomic_load(flags + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+            v2 = ld_agent_u64(q);
+            __builtin_amdgcn_s_sleep(1);
+        }
+    } else {
+        for (unsigned it = 0; it < kGsSpinLimit; ++it) {
+            const unsigned long long v = ld_agent_u64(q);
+            if (v != kGsSentinel) return __longlong_as_double((long long)v);
+            if ((it & 255u) == 255u && __hip_atomic_load(flags + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+            __builtin_amdgcn_s_sleep(4);
+        }
     }
     if (__hip_atomic_exchange(flags + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
         // first to give up: leave a breadcrumb (which workgroup, which thread, low address bits)
@@ -304,12 +336,13 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
             y = p.py[64 * s + lane];
             z = p.pz[64 * s + lane];
         };
-        auto fetch_mu = [&](int s) {  // mu_s -> smu[q][atom]; false on a give-up
+        auto fetch_mu = [&](int s) {  // mu_s -> smu[q][atom] (the published layout); false on a give-up
             __syncthreads();          // the previous tile's readers are done with smu
             if (tid < 192) {
                 bool ok = true;
-                const double v = poll_value(p.mu_new + 192 * (size_t)s + tid, p.flags, ok);
-                smu[(tid % 3) * 64 + tid / 3] = v;
+                // the last few sources before the neighbour are nearly on the critical path
+                smu[tid] = (t - s <= 4) ? poll_value<true>(p.mu_new + 192 * (size_t)s + tid, p.flags, ok)
+                                        : poll_value<false>(p.mu_new + 192 * (size_t)s + tid, p.flags, ok);
                 if (!ok) s_ok = 0;
             }
             __syncthreads();
@@ -372,8 +405,7 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
         __syncthreads();
         if (tid < 192) {
             bool ok = true;
-            const double v = poll_value(p.mu_new + 192 * (size_t)(t - 1) + tid, p.flags, ok);
-            smu[(tid % 3) * 64 + tid / 3] = v;
+            smu[tid] = poll_value<true>(p.mu_new + 192 * (size_t)(t - 1) + tid, p.flags, ok);
             if (!ok) s_ok = 0;
         }
         __syncthreads();
@@ -431,14 +463,25 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
         zred[(w * 3 + 2) * 64 + lane] = a1z;
     }
     __syncthreads();
-    if (tid < 192 && t != p.fault_block) {
-        double mu = f_v;
+    // publish: 96 lanes, two adjacent elements of the planar block vector each (same component q, atoms i, i + 1)
+    if (tid < 96) {
+        const int e = 2 * tid;
+        double2 mu = *reinterpret_cast<const double2 *>(smu + e);  // v_t
+        const int q = e >> 6, i = e & 63;
 #pragma unroll
-        for (int g = 0; g < kChainWaves; ++g) mu += zred[(g * 3 + w) * 64 + lane];
-        const int k = 64 * t + lane;
-        st_agent(p.mu_new + 3 * (size_t)k + w, mu);
+        for (int g = 0; g < kChainWaves; ++g) {
+            const double2 z = *reinterpret_cast<const double2 *>(zred + (g * 3 + q) * 64 + i);
+            mu.x += z.x;
+            mu.y += z.y;
+        }
+        if (t != p.fault_block) st_agent16(p.mu_new + 192 * (size_t)t + e, mu.x, mu.y);
+        *reinterpret_cast<double2 *>(smu + e) = mu;
+    }
+    __syncthreads();
+    if (tid < 192) {
         // E_induced of the atom when it was updated (thole_iterative.c:44-46): mu = alpha (e + E_ind)
-        p.y[3 * k + w] = (f_al != 0.0) ? mu / f_al - f_es : 0.0;
+        const int k = 64 * t + lane;
+        p.y[3 * k + w] = (f_al != 0.0) ? smu[w * 64 + lane] / f_al - f_es : 0.0;
     }
 }
 

@@ -448,7 +448,7 @@ def test_ranked_walk_is_speculated_and_repeated_when_the_metric_changes():
     moves = [(3, pos[15:20] + np.array([0.2, -0.1, 0.1])),            # ordinary displacement
              (20, target + np.array([0.3, 0.0, 0.0])),                # molecule 20 lands on molecule 7: walk changes
              (31, pos[5 * 31:5 * 31 + 5] + np.array([-0.1, 0.2, 0.0])),  # ordinary, with the changed walk resident
-             (20, pos[100:105]),                                      # pulled back: walk changes again
+             (20, s["pos"][100:105].copy()),                          # pulled back: walk changes again
              (40, pos[200:205] + np.array([0.1, 0.1, -0.2]))]
     orders = []
     for mol, new in moves:
