@@ -182,6 +182,8 @@ struct mpmc_hip_ctx {
     bool all_dirty = true;
     int opt_incremental = 1, opt_overlap = 1, opt_symmetric = 1, opt_persistent_gs = 1;
     int opt_gs_fault_sweep = 0;
+    int opt_gs_stamps = 0;                 // diagnostic: time stamps inside the chain kernel (printed by the sweep)
+    unsigned long long *d_stamps = nullptr;
     int gs_sweeps_this_call = 0;
     int opt_pair_coef = 1;  // Jacobi/Palmo sweeps on pair coefficients (0: on the expanded A matrix)
     int opt_incremental_pairs = 1;  // LJ/Ewald-real and static-field tile partials persist between calls
@@ -318,6 +320,7 @@ static DevBox dev_box(const mpmc_hip_ctx *c) {
 }
 
 static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+static void (*chain_kernel_of(int ortho))(GsChain);  // engine_polar.inc
 
 // running maximum of |coordinate| (device_common.h: above kScreen32MaxCoord the pair / field screens switch
 // from fp32 to fp64 displacements); a NaN coordinate switches too
@@ -451,6 +454,8 @@ extern "C" int mpmc_hip_set_option(mpmc_hip_ctx *c, const char *name, int value)
         c->opt_persistent_gs = value;
     else if (!strcmp(name, "speculative_ranking"))
         c->opt_spec_rank = value;  // 0: polar_gs_ranked asks the host for the sweep order in every call (A/B)
+    else if (!strcmp(name, "gs_stamps"))
+        c->opt_gs_stamps = value;  // diagnostic: the next Gauss-Seidel sweeps print where a block's time goes (slow)
     else if (!strcmp(name, "gs_fault_sweep"))
         c->opt_gs_fault_sweep = value;  // test hook: in Gauss-Seidel sweep number `value` (1-based) block 1 never publishes
     else if (!strcmp(name, "pair_coefficients")) {
@@ -494,10 +499,9 @@ extern "C" int mpmc_hip_create(mpmc_hip_ctx **out, int device, int max_atoms) {
     mpmc_hip_default_params(&c->par);
     const size_t np = (size_t)c->max_npad;
     c->num_cus = prop.multiProcessorCount;
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(gs_chain_kernel<0>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, kChainLds));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(gs_chain_kernel<1>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, kChainLds));
+    for (int o = 0; o < 2; ++o)
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_kernel_of(o)),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, kChainLds));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(gs_block_inverse_kernel<0>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, kInverseLds));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(gs_block_inverse_kernel<1>),
@@ -546,7 +550,7 @@ extern "C" int mpmc_hip_create(mpmc_hip_ctx **out, int device, int max_atoms) {
         DALLOC(v.mu0, 3 * np, double);
         DALLOC(v.mu1, 3 * np, double);
         DALLOC(v.munew, 3 * np, double);
-        DALLOC(v.mupub, 3 * np, double);
+        DALLOC(v.mupub, 3 * np + 192, double);  // (+ one spare block: target of the chain kernel's rehearsal stores)
         DALLOC(v.y, 3 * np, double);
         DALLOC(v.efind, 3 * np, double);
         DALLOC(v.efchg, 3 * np, double);

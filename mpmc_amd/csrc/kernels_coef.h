@@ -13,7 +13,11 @@
 //
 // Storage: 64 x 64-pair tiles (ti <= tj), "rotated" so that the access of the sweep is coalesced:
 //     element (l, s) of tile (ti, tj) is the pair  i = 64 ti + l,  j = 64 tj + ((l + s) & 63)
-//     C[((ti * ntld + tj) * 64 + s) * 64 + l] = {c3, c5}          (ntld = tiles the view can grow to)
+//     C[(coef_tile_index(ti, tj) * 64 + s) * 64 + l] = {c3, c5}
+// The tiles are ordered by COLUMN block (tj * ntld + ti; ntld = tiles the view can grow to): the Gauss-Seidel chain
+// kernel's workgroup for block t streams the tiles (s, t), s = 0 .. t-2, one after the other, and with this order
+// they are contiguous (64 KB each) instead of ntld x 64 KB = 4 MB apart -- one page / DRAM row after the other
+// instead of a TLB miss per tile.  The sweep kernels visit every tile once in any case.
 // At step s lane l of a wave works on row atom l and column atom (l + s) & 63: the row sums stay in
 // the lane, the column sums travel one lane per step (DPP wave_rol:1), the column atoms' coordinates
 // and dipoles are read from LDS at a rotating, conflict-free index.  A diagonal tile holds every
@@ -28,6 +32,7 @@ namespace mpmc {
 constexpr int kCoefTile = 64;        // atoms per tile edge (= one wave)
 constexpr int kCoefWaves = 4;        // waves per sweep workgroup; each takes 64/4 = 16 steps of a tile
 constexpr int kCoefSteps = kCoefTile / kCoefWaves;
+__host__ __device__ __forceinline__ size_t coef_tile_index(int ti, int tj, int ntld) { return (size_t)tj * ntld + ti; }
 
 // Displacement of the minimum image.  The lattice translation comes from the same un-contracted
 // arithmetic as minimum_image() (bit-identical rint() arguments => identical image, also on ties);
@@ -104,7 +109,7 @@ __global__ __launch_bounds__(64 * kCoefWaves) void build_coef_kernel(DevAtoms a,
     const double xi = a.x[64 * ti + l], yi = a.y[64 * ti + l], zi = a.z[64 * ti + l];
     const bool vi = a.flags[64 * ti + l] & kValid;
     __syncthreads();
-    double2 *tile = C + (size_t)(ti * ntld + tj) * (kCoefTile * kCoefTile);
+    double2 *tile = C + coef_tile_index(ti, tj, ntld) * (kCoefTile * kCoefTile);
     for (int s = kCoefSteps * w; s < kCoefSteps * (w + 1); ++s) {
         const int jj = (l + s) & 63;
         double c3 = 0.0, c5 = 0.0, dx, dy, dz;
@@ -134,11 +139,11 @@ __global__ __launch_bounds__(64) void update_coef_kernel(DevAtoms a, DevBox bx, 
     const double2 v = make_double2(c3, c5);
     const size_t tsz = kCoefTile * kCoefTile;
     if (ta < tk) {
-        C[(size_t)(ta * ntld + tk) * tsz + ((lk - la) & 63) * 64 + la] = v;
+        C[coef_tile_index(ta, tk, ntld) * tsz + ((lk - la) & 63) * 64 + la] = v;
     } else if (ta > tk) {
-        C[(size_t)(tk * ntld + ta) * tsz + ((la - lk) & 63) * 64 + lk] = v;
+        C[coef_tile_index(tk, ta, ntld) * tsz + ((la - lk) & 63) * 64 + lk] = v;
     } else {
-        double2 *tile = C + (size_t)(ta * ntld + ta) * tsz;
+        double2 *tile = C + coef_tile_index(ta, ta, ntld) * tsz;
         tile[((lk - la) & 63) * 64 + la] = v;
         tile[((la - lk) & 63) * 64 + lk] = v;
     }
@@ -345,7 +350,7 @@ __global__ __launch_bounds__(64 * kCoefWaves) void pair_sweep_kernel(const doubl
     const int i = 64 * ti + l;
     const double xi = x[i], yi = y[i], zi = z[i];
     const double mix = mu[3 * i], miy = mu[3 * i + 1], miz = mu[3 * i + 2];
-    const double2 *tile = C + (size_t)(ti * ntld + tj) * (kCoefTile * kCoefTile) + (size_t)(kCoefSteps * w) * 64 + l;
+    const double2 *tile = C + coef_tile_index(ti, tj, ntld) * (kCoefTile * kCoefTile) + (size_t)(kCoefSteps * w) * 64 + l;
     double2 c[kCoefSteps];
 #pragma unroll
     for (int k = 0; k < kCoefSteps; ++k) c[k] = stream_load_coef(tile + 64 * k);
@@ -430,7 +435,7 @@ __global__ __launch_bounds__(64 * kCoefWaves) void pair_upper_kernel(const doubl
     }
     const int i = 64 * ti + l;
     const double xi = x[i], yi = y[i], zi = z[i];
-    const double2 *tile = C + (size_t)(ti * ntld + tj) * (kCoefTile * kCoefTile) + (size_t)(kCoefSteps * w) * 64 + l;
+    const double2 *tile = C + coef_tile_index(ti, tj, ntld) * (kCoefTile * kCoefTile) + (size_t)(kCoefSteps * w) * 64 + l;
     double2 c[kCoefSteps];
 #pragma unroll
     for (int k = 0; k < kCoefSteps; ++k) c[k] = stream_load_coef(tile + 64 * k);

@@ -47,14 +47,18 @@ constexpr unsigned long long kGsSentinel = 0x7ff8dead7ff8deadull;  // a NaN no a
 //     g <= 30:  l >  g : M[row atom l     ][column atom g     ]
 //               l <= g : M[row atom 63 - l][column atom 62 - g]
 //     g == 31:  l > 31 : M[row atom l][column atom 31],  l <= 31 : 0
-//   Minv[((t * 32 + g) * 9 + e) * 64 + l]
 // (column atom c has 63 - c rows below it: columns c and 62 - c together fill exactly 64 lanes.)
+// Wave w of the chain kernel takes the groups g = w + 8 k (k = 0..3); its 36 entries per lane, f = 9 k + e, are
+// stored as 18 adjacent pairs so that they are read with 16-byte LDS loads (ds_read_b128 runs at 256 B/clk, the
+// two-address forms the compiler makes of 8-byte loads at 128 B/clk -- and this read is on the sweep's critical path):
+//   Minv[t * 18432 + ((w * 18 + f / 2) * 64 + l) * 2 + f % 2]
 constexpr int kMinvGroups = 32;
 constexpr int kMinvDoubles = kMinvGroups * 9 * 64;  // 18 432 per block (147 456 B)
 __device__ __forceinline__ int minv_index(int row, int col, int e) {  // row > col, atoms within the block
     const int g = (col <= 31) ? col : 62 - col;
     const int l = (col <= 31) ? row : 63 - row;
-    return (g * 9 + e) * 64 + l;
+    const int w = g & 7, f = 9 * (g >> 3) + e;
+    return ((w * 18 + (f >> 1)) * 64 + l) * 2 + (f & 1);
 }
 
 // ---- expanded neighbour tile T(t, t-1): target atom i of block t, source atom j of block t-1
@@ -74,6 +78,7 @@ struct GsChain {
     unsigned *flags;   // [0] ticket counter (zeroed per sweep), [1] sticky error word, [2..4] breadcrumbs
     DevBox bx;
     int fault_block;   // test hook: the workgroup of this block never publishes (-1 = off)
+    unsigned long long *stamps;  // diagnostic (option "gs_stamps"): [nb][16] s_memrealtime stamps of one sweep, or null
 };
 
 // offset of column / row j in a packed strict triangle of a 64-atom block: j 63 - j (j - 1) / 2
@@ -101,13 +106,14 @@ __device__ __forceinline__ unsigned long long ld_agent_u64(const unsigned long l
 template <bool URGENT>
 __device__ __forceinline__ double poll_value(const double *p, unsigned *flags, bool &ok) {
     const unsigned long long *q = reinterpret_cast<const unsigned long long *>(p);
+    const unsigned limit = kGsSpinLimit;
     if (URGENT) {
         unsigned long long v0 = ld_agent_u64(q);
         __builtin_amdgcn_s_sleep(1);
         unsigned long long v1 = ld_agent_u64(q);
         __builtin_amdgcn_s_sleep(1);
         unsigned long long v2 = ld_agent_u64(q);
-        for (unsigned it = 0; it < 4 * kGsSpinLimit; ++it) {
+        for (unsigned it = 0; it < 4 * limit; ++it) {
             if (v0 != kGsSentinel) return __longlong_as_double((long long)v0);
             v0 = v1;
             v1 = v2;
@@ -116,7 +122,7 @@ __device__ __forceinline__ double poll_value(const double *p, unsigned *flags, b
             __builtin_amdgcn_s_sleep(1);
         }
     } else {
-        for (unsigned it = 0; it < kGsSpinLimit; ++it) {
+        for (unsigned it = 0; it < limit; ++it) {
             const unsigned long long v = ld_agent_u64(q);
             if (v != kGsSentinel) return __longlong_as_double((long long)v);
             if ((it & 255u) == 255u && __hip_atomic_load(flags + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
@@ -132,6 +138,12 @@ __device__ __forceinline__ double poll_value(const double *p, unsigned *flags, b
     ok = false;
     return 0.0;
 }
+
+// diagnostic time stamp (100 MHz constant clock, comparable across CUs); thread 0 of the workgroup only
+#define GS_STAMP(slot)                                                                       \
+    do {                                                                                     \
+        if (p.stamps && tid == 0) p.stamps[(size_t)t * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
 
 // 64-lane rotation by one the other way: lane l receives the value of lane (l - 1) & 63 (wave_ror:1)
 __device__ __forceinline__ double wave_rotate_up(double v) {
@@ -158,7 +170,7 @@ __global__ __launch_bounds__(256) void gs_neighbor_tensor_kernel(const double2 *
                                                                   double2 *__restrict__ Tnb) {
     const int t = (sel.n > 0) ? sel.blk[blockIdx.x] : (int)blockIdx.x + 1;
     if (t < 1) return;
-    const double2 *tile = C + (size_t)((t - 1) * ntld + t) * (kCoefTile * kCoefTile);
+    const double2 *tile = C + coef_tile_index(t - 1, t, ntld) * (kCoefTile * kCoefTile);
     double2 *out = Tnb + (size_t)t * kTnbDouble2;
     const int i = threadIdx.x & 63;
     const double xi = px[64 * t + i], yi = py[64 * t + i], zi = pz[64 * t + i];
@@ -208,7 +220,7 @@ __global__ __launch_bounds__(256) void gs_block_inverse_kernel(const double2 *__
     }
     __syncthreads();
     // expand the strictly lower triangle: pair (a, b), a > b, is element (l = b, s = a - b) of the diagonal tile
-    const double2 *tile = C + (size_t)(t * ntld + t) * (kCoefTile * kCoefTile);
+    const double2 *tile = C + coef_tile_index(t, t, ntld) * (kCoefTile * kCoefTile);
     for (int s = 1 + w; s < 64; s += 4) {
         const int b = lane, a = lane + s;
         if (a < 64) {
@@ -271,7 +283,7 @@ constexpr int kChainLds = kChainLdsDoubles * 8;  // 162 832 B of the 163 840 a w
 template <int ORTHO>
 __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *sM = lds;                                   // [32][9][64] folded inverse of this block
+    double *sM = lds;                                   // [8 waves][18][64] double2: folded inverse of this block
     double *zred = sM + kMinvDoubles;                   // [8][3][64] per-wave partial sums
     double *smu = zred + kChainWaves * 3 * 64;          // [3][64] dipoles of the source block just polled; later v_t
     double *spos = smu + 3 * 64;                        // [3][64] coordinates of this (target) block
@@ -287,6 +299,8 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
     const int t = s_t;
     if (t >= p.nb) return;
     const size_t tsz = kCoefTile * kCoefTile;
+    GS_STAMP(0);
+    if (p.stamps && tid == 0) p.stamps[(size_t)t * 16 + 12] = __builtin_amdgcn_s_memtime();  // shader clock, for the effective MHz
 
     // ---- stage M_t (folded layout, 16-B loads) and the target block's coordinates
     {
@@ -320,6 +334,7 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
             for (int h = 0; h < 3; ++h) tn[k][h] = src[((w + 8 * k) * 3 + h) * 64];
     }
     __syncthreads();
+    GS_STAMP(1);
 
     // ---- sources s = 0 .. t-2 from the pair coefficients, as they are published
     double ax = 0.0, ay = 0.0, az = 0.0;  // this wave's share of sum_s T(t,s) mu_s; alignment tracked by `fwd_done`
@@ -329,7 +344,7 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
         double2 cA[8], cB[8];
         double sxA = 0, syA = 0, szA = 0, sxB = 0, syB = 0, szB = 0;
         auto load_tile = [&](int s, double2 (&c)[8], double &x, double &y, double &z) {
-            const double2 *tl = p.C + (size_t)(s * p.ntld + t) * tsz + (size_t)(8 * w) * 64 + lane;
+            const double2 *tl = p.C + coef_tile_index(s, t, p.ntld) * tsz + (size_t)(8 * w) * 64 + lane;
 #pragma unroll
             for (int k = 0; k < 8; ++k) c[k] = tl[64 * k];
             x = p.px[64 * s + lane];
@@ -378,12 +393,16 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
         for (int s = 0; s < ns; s += 2) {
             if (s + 1 < ns) load_tile(s + 1, cB, sxB, syB, szB);
             if (!fetch_mu(s)) return;
+            if (s >= ns - 2) GS_STAMP(s == ns - 1 ? 4 : 2);
             tile_product(cA, sxA, syA, szA, true);
+            if (s >= ns - 2) GS_STAMP(s == ns - 1 ? 5 : 3);
             last_forward = true;
             if (s + 1 < ns) {
                 if (s + 2 < ns) load_tile(s + 2, cA, sxA, syA, szA);
                 if (!fetch_mu(s + 1)) return;
+                if (s + 1 >= ns - 2) GS_STAMP(s + 1 == ns - 1 ? 4 : 2);
                 tile_product(cB, sxB, syB, szB, false);
+                if (s + 1 >= ns - 2) GS_STAMP(s + 1 == ns - 1 ? 5 : 3);
                 last_forward = false;
             }
         }
@@ -400,31 +419,46 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
     ay = zred[(w * 3 + 1) * 64 + lane];
     az = zred[(w * 3 + 2) * 64 + lane];
 
-    // ---- the critical path: mu_{t-1} -> neighbour product -> v_t -> M_t v_t -> publish
+    // ---- the critical path: mu_{t-1} -> neighbour product -> v_t -> M_t v_t -> publish.
+    // Measured (in-kernel stamps, option gs_stamps, and same-box A/B runs): per block ~0.85 us of
+    // hand-off (publication to "all 192 doubles in the consumer's LDS") + ~1.8 us for the barrier-separated stages
+    // (six barriers in the first version of this section, three now).  The stages'
+    // ARITHMETIC is ~0.1 us of that -- removing both block products changed the sweep by 3 % --, so what a block
+    // costs is LDS round trips and barriers at two waves per SIMD, not flops, and the on-the-fly sources above are
+    // entirely hidden (emptying that loop changed nothing).  Tried and measured slower: every wave polling for itself
+    // (+14 %), v_readlane broadcasts instead of uniform LDS reads (+12 %), a rehearsal pass to warm the instruction
+    // cache (+17 %).  Fewer stages need the neighbour product and the inverse folded into one cached matrix
+    // (M_t D T(t,t-1), 295 KB per block): not done.
+    double f_v = 0.0;
+    {
+    GS_STAMP(6);
     if (t >= 1) {
-        __syncthreads();
-        if (tid < 192) {
+        // Every wave fetches the 24 doubles IT needs (its 8 source atoms x 3 components) with its first 24 lanes and
+        // spreads them through 24 words of LDS that only this wave touches: no workgroup barrier between the
+        // hand-off and the product (a wave's LDS operations execute in order), same number of polling lanes (192)
+        // as a staged copy of the whole vector.
+        double *wsm = smu + 24 * w;
+        if (lane < 24) {
             bool ok = true;
-            smu[tid] = poll_value<true>(p.mu_new + 192 * (size_t)(t - 1) + tid, p.flags, ok);
+            const int j = w + 8 * (lane / 3), q = lane % 3;
+            wsm[lane] = poll_value<true>(p.mu_new + 192 * (size_t)(t - 1) + 64 * q + j, p.flags, ok);
             if (!ok) s_ok = 0;
         }
-        __syncthreads();
-        if (!s_ok) return;
+        GS_STAMP(7);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int j = w + 8 * k;
-            const double mx = smu[j], my = smu[64 + j], mz = smu[128 + j];  // wave-uniform: broadcast reads
-            ax = fma(tn[k][1].x, mz, fma(tn[k][0].y, my, fma(tn[k][0].x, mx, ax)));
-            ay = fma(tn[k][2].x, mz, fma(tn[k][1].y, my, fma(tn[k][0].y, mx, ay)));
-            az = fma(tn[k][2].y, mz, fma(tn[k][2].x, my, fma(tn[k][1].x, mx, az)));
+            const double bx_ = wsm[3 * k], by_ = wsm[3 * k + 1], bz_ = wsm[3 * k + 2];  // wave-uniform: broadcast reads
+            ax = fma(tn[k][1].x, bz_, fma(tn[k][0].y, by_, fma(tn[k][0].x, bx_, ax)));
+            ay = fma(tn[k][2].x, bz_, fma(tn[k][1].y, by_, fma(tn[k][0].y, bx_, ay)));
+            az = fma(tn[k][2].y, bz_, fma(tn[k][2].x, by_, fma(tn[k][1].x, bx_, az)));
         }
     }
-    __syncthreads();  // (everyone is done with smu and with the realignment reads of zred)
-    zred[(w * 3 + 0) * 64 + lane] = ax;
+    zred[(w * 3 + 0) * 64 + lane] = ax;  // (this wave's own rows: last read by this wave, above)
     zred[(w * 3 + 1) * 64 + lane] = ay;
     zred[(w * 3 + 2) * 64 + lane] = az;
-    __syncthreads();
-    double f_v = 0.0;
+    __syncthreads();  // partial sums complete; every wave is also done with its words of smu, which v_t overwrites
+    if (!s_ok) return;
+    GS_STAMP(8);
     if (tid < 192) {
         double sum = 0.0;
 #pragma unroll
@@ -433,26 +467,32 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
         smu[w * 64 + lane] = f_v;
     }
     __syncthreads();
+    GS_STAMP(9);
     // M_t v_t: wave w takes the column groups g = w, w + 8, w + 16, w + 24 of the folded inverse
     {
+        double2 mm[18];
+        const double2 *mp = reinterpret_cast<const double2 *>(sM) + (size_t)(w * 18) * 64 + lane;
+#pragma unroll
+        for (int f2 = 0; f2 < 18; ++f2) mm[f2] = mp[f2 * 64];
         double a1x = 0.0, a1y = 0.0, a1z = 0.0, a2x = 0.0, a2y = 0.0, a2z = 0.0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int g = w + 8 * k;
-            const bool r1 = lane > g;                // role 1: (row lane, column g); role 2: (row 63-lane, column 62-g)
+            const bool r1 = lane > g;  // role 1: (row lane, column g); role 2: (row 63 - lane, column 62 - g)
             const int c1 = g, c2 = (g <= 30) ? 62 - g : g;
-            const double vx = r1 ? smu[c1] : smu[c2], vy = r1 ? smu[64 + c1] : smu[64 + c2],
-                         vz = r1 ? smu[128 + c1] : smu[128 + c2];
-            const double *m = sM + (size_t)(g * 9) * 64 + lane;
-            const double tx = fma(m[2 * 64], vz, fma(m[1 * 64], vy, m[0] * vx));
-            const double ty = fma(m[5 * 64], vz, fma(m[4 * 64], vy, m[3 * 64] * vx));
-            const double tz = fma(m[8 * 64], vz, fma(m[7 * 64], vy, m[6 * 64] * vx));
-            a1x += r1 ? tx : 0.0;
-            a1y += r1 ? ty : 0.0;
-            a1z += r1 ? tz : 0.0;
-            a2x += r1 ? 0.0 : tx;
-            a2y += r1 ? 0.0 : ty;
-            a2z += r1 ? 0.0 : tz;
+            // the inactive role's vector is zeroed instead of selecting results
+            const double b1x = smu[c1], b1y = smu[64 + c1], b1z = smu[128 + c1];
+            const double b2x = smu[c2], b2y = smu[64 + c2], b2z = smu[128 + c2];
+            const double x1 = r1 ? b1x : 0.0, y1 = r1 ? b1y : 0.0, z1 = r1 ? b1z : 0.0;
+            const double x2 = r1 ? 0.0 : b2x, y2 = r1 ? 0.0 : b2y, z2 = r1 ? 0.0 : b2z;
+#define MINV_E(e) (((9 * k + (e)) & 1) ? mm[(9 * k + (e)) >> 1].y : mm[(9 * k + (e)) >> 1].x)
+            a1x = fma(MINV_E(2), z1, fma(MINV_E(1), y1, fma(MINV_E(0), x1, a1x)));
+            a1y = fma(MINV_E(5), z1, fma(MINV_E(4), y1, fma(MINV_E(3), x1, a1y)));
+            a1z = fma(MINV_E(8), z1, fma(MINV_E(7), y1, fma(MINV_E(6), x1, a1z)));
+            a2x = fma(MINV_E(2), z2, fma(MINV_E(1), y2, fma(MINV_E(0), x2, a2x)));
+            a2y = fma(MINV_E(5), z2, fma(MINV_E(4), y2, fma(MINV_E(3), x2, a2y)));
+            a2z = fma(MINV_E(8), z2, fma(MINV_E(7), y2, fma(MINV_E(6), x2, a2z)));
+#undef MINV_E
         }
         // role-2 sums belong to row 63 - lane: mirror them across the wave
         a1x += __shfl(a2x, 63 - lane, 64);
@@ -463,6 +503,7 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
         zred[(w * 3 + 2) * 64 + lane] = a1z;
     }
     __syncthreads();
+    GS_STAMP(10);
     // publish: 96 lanes, two adjacent elements of the planar block vector each (same component q, atoms i, i + 1)
     if (tid < 96) {
         const int e = 2 * tid;
@@ -478,6 +519,9 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
         *reinterpret_cast<double2 *>(smu + e) = mu;
     }
     __syncthreads();
+    }
+    GS_STAMP(11);
+    if (p.stamps && tid == 0) p.stamps[(size_t)t * 16 + 13] = __builtin_amdgcn_s_memtime();
     if (tid < 192) {
         // E_induced of the atom when it was updated (thole_iterative.c:44-46): mu = alpha (e + E_ind)
         const int k = 64 * t + lane;
