@@ -125,12 +125,20 @@ void mpmc_hip_destroy(mpmc_hip_ctx *ctx);
  *                          polarization chain;
  *   "symmetric_sweep"     (default 1; with pair_coefficients = 0): sweeps read only the upper triangle of A and
  *                          use every element for both products; 0 = full-matrix sweep; 2 = also below 2048 atoms;
- *   "timing"              (default 1): 0 = record no HIP events; 1 = time the sweep kernels of every 32nd
- *                          call ("timing_interval" changes the 32; plus an empty event pair for calibration); 2 = time every kernel class of every
- *                          call (each event pair costs ~5 microseconds of stream time);
- *   "persistent_gs"       (default 2): Gauss-Seidel lower-triangle phase as one persistent kernel (spine + owner
- *                          workgroups); 2 = the spine takes the neighbour block from the pair coefficients when the
- *                          view has >= 20 blocks, 3 = always, 1 = never; 0 = two launches per 64-atom block;
+ *   "timing"              (default 1): 0 = record no HIP events; 1 = the sweep kernels (pair_sweep_kernel /
+ *                          gs_chain_kernel) of every 32nd call ("timing_interval" changes the 32) are launched with a
+ *                          start / stop event pair that carries the dispatch's own begin / end timestamps; 2 = time
+ *                          every kernel class of every call (an event pair recorded AROUND a launch costs ~5
+ *                          microseconds of stream time);
+ *   "persistent_gs"       (default 1): Gauss-Seidel lower-triangle phase as one persistent launch (gs_chain_kernel:
+ *                          a workgroup per 64-atom block in ticket order, cached block inverses, pair coefficients);
+ *                          0 = the literal forward substitution on the expanded matrix, two launches per block;
+ *   "speculative_ranking" (default 1): polar_gs_ranked calls are enqueued for the ranked walk of the previous call
+ *                          and checked on the device (repeated with the host sorting when the metric changed);
+ *                          0 = the host sorts the ranking metric in every call;
+ *   "gs_stamps"           diagnostic: the next `value` Gauss-Seidel sweeps print in-kernel time stamps per block;
+ *   "gs_fault_sweep"      test hook: in sweep number `value` of a call one block is never published (the call must
+ *                          fail with a hand-off error, tests/test_gpu_parity.py);
  *   "step_graph"          (default 0): replay a steady-state MC step as a HIP graph (bit-identical; measured
  *                          slower than direct launches on ROCm 7.2). */
 int mpmc_hip_set_option(mpmc_hip_ctx *ctx, const char *name, int value);
