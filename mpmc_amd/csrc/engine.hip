@@ -182,6 +182,7 @@ struct mpmc_hip_ctx {
     bool all_dirty = true;
     int opt_incremental = 1, opt_overlap = 1, opt_symmetric = 1, opt_persistent_gs = 1;
     int opt_gs_fault_sweep = 0;
+    int opt_gs_ablate = 0;                 // timing-only ablations of the chain kernel (wrong results; tools/gs_ablate.py)
     int opt_gs_stamps = 0;                 // diagnostic: time stamps inside the chain kernel (printed by the sweep)
     unsigned long long *d_stamps = nullptr;
     int gs_sweeps_this_call = 0;
@@ -454,6 +455,8 @@ extern "C" int mpmc_hip_set_option(mpmc_hip_ctx *c, const char *name, int value)
         c->opt_persistent_gs = value;
     else if (!strcmp(name, "speculative_ranking"))
         c->opt_spec_rank = value;  // 0: polar_gs_ranked asks the host for the sweep order in every call (A/B)
+    else if (!strcmp(name, "gs_ablate"))
+        c->opt_gs_ablate = value;
     else if (!strcmp(name, "gs_stamps"))
         c->opt_gs_stamps = value;  // diagnostic: the next Gauss-Seidel sweeps print where a block's time goes (slow)
     else if (!strcmp(name, "gs_fault_sweep"))

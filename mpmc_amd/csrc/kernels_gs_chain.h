@@ -78,6 +78,8 @@ struct GsChain {
     unsigned *flags;   // [0] ticket counter (zeroed per sweep), [1] sticky error word, [2..4] breadcrumbs
     DevBox bx;
     int fault_block;   // test hook: the workgroup of this block never publishes (-1 = off)
+    int ablate;        // TIMING-ONLY ablations (option "gs_ablate", results are wrong): bit 0 no source loop, bit 1 no
+                       // tile loads, bit 2 no polls in the source loop, bit 3 the critical section only republishes
     unsigned long long *stamps;  // diagnostic (option "gs_stamps"): [nb][16] s_memrealtime stamps of one sweep, or null
 };
 
@@ -93,6 +95,11 @@ __device__ __forceinline__ void st_agent16(double *p, double a, double b) {
     typedef double __attribute__((ext_vector_type(2))) d2_t;
     const d2_t v = {a, b};
     asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+
+__device__ __forceinline__ void st_agent(double *p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __device__ __forceinline__ unsigned long long ld_agent_u64(const unsigned long long *q) {
@@ -316,14 +323,6 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
         const double *src = (tid < 64) ? p.px : (tid < 128 ? p.py : p.pz);
         spos[tid] = src[64 * t + (tid & 63)];
     }
-    // per-atom operands of the final steps: thread (component q = tid / 64 of atom i = tid % 64), tid < 192
-    double f_al = 0.0, f_es = 0.0, f_yu = 0.0;
-    if (tid < 192) {
-        const int k = 64 * t + lane;
-        f_al = p.alpha[k];
-        f_es = p.es[3 * k + w];
-        f_yu = p.y[3 * k + w];
-    }
     // ---- neighbour tensor tile (t, t-1) into registers: wave w takes the sources j = w, w + 8, ...
     double2 tn[8][3];
     if (t >= 1) {
@@ -338,26 +337,43 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
 
     // ---- sources s = 0 .. t-2 from the pair coefficients, as they are published
     double ax = 0.0, ay = 0.0, az = 0.0;  // this wave's share of sum_s T(t,s) mu_s; alignment tracked by `fwd_done`
-    const int ns = t - 1;
+    const int ns = (p.ablate & 1) ? 0 : t - 1;
     bool last_forward = false;
     {
         double2 cA[8], cB[8];
         double sxA = 0, syA = 0, szA = 0, sxB = 0, syB = 0, szB = 0;
         auto load_tile = [&](int s, double2 (&c)[8], double &x, double &y, double &z) {
             const double2 *tl = p.C + coef_tile_index(s, t, p.ntld) * tsz + (size_t)(8 * w) * 64 + lane;
+            if (p.ablate & 2) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) c[k] = make_double2(1e-3, 1e-4);
+                x = y = z = 1.0 * lane;
+                return;
+            }
 #pragma unroll
             for (int k = 0; k < 8; ++k) c[k] = tl[64 * k];
             x = p.px[64 * s + lane];
             y = p.py[64 * s + lane];
             z = p.pz[64 * s + lane];
         };
+        // The dipoles of the next source are requested BEFORE that source's coefficient loads (a wave's loads complete
+        // in order: a poll issued behind 64 KB of tile loads waits for all of them -- measured, that made a tile cost
+        // 2.7 us instead of 1.5) and looked at after the current tile's arithmetic; a workgroup that runs behind the
+        // front finds them valid and never waits.
+        unsigned long long spec = kGsSentinel;
+        auto spec_issue = [&](int s) {
+            if (tid < 192 && !(p.ablate & 4)) spec = ld_agent_u64(reinterpret_cast<const unsigned long long *>(p.mu_new) + 192 * (size_t)s + tid);
+        };
         auto fetch_mu = [&](int s) {  // mu_s -> smu[q][atom] (the published layout); false on a give-up
+            if (p.ablate & 4) return true;
             __syncthreads();          // the previous tile's readers are done with smu
             if (tid < 192) {
                 bool ok = true;
-                // the last few sources before the neighbour are nearly on the critical path
-                smu[tid] = (t - s <= 4) ? poll_value<true>(p.mu_new + 192 * (size_t)s + tid, p.flags, ok)
-                                        : poll_value<false>(p.mu_new + 192 * (size_t)s + tid, p.flags, ok);
+                double v = __longlong_as_double((long long)spec);
+                if (spec == kGsSentinel)  // not there yet: poll (urgently when close to the neighbour)
+                    v = (t - s <= 4) ? poll_value<true>(p.mu_new + 192 * (size_t)s + tid, p.flags, ok)
+                                     : poll_value<false>(p.mu_new + 192 * (size_t)s + tid, p.flags, ok);
+                smu[tid] = v;
                 if (!ok) s_ok = 0;
             }
             __syncthreads();
@@ -389,10 +405,14 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
                 az = fma(wi, dz, fma(c3, mz, az));
             }
         };
-        if (ns > 0) load_tile(0, cA, sxA, syA, szA);
+        if (ns > 0) {
+            spec_issue(0);
+            load_tile(0, cA, sxA, syA, szA);
+        }
+        if (ns > 1) load_tile(1, cB, sxB, syB, szB);
         for (int s = 0; s < ns; s += 2) {
-            if (s + 1 < ns) load_tile(s + 1, cB, sxB, syB, szB);
             if (!fetch_mu(s)) return;
+            if (s + 1 < ns) spec_issue(s + 1);  // (older than the tile loads issued below: lands during the arithmetic)
             if (s >= ns - 2) GS_STAMP(s == ns - 1 ? 4 : 2);
             tile_product(cA, sxA, syA, szA, true);
             if (s >= ns - 2) GS_STAMP(s == ns - 1 ? 5 : 3);
@@ -400,10 +420,12 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
             if (s + 1 < ns) {
                 if (s + 2 < ns) load_tile(s + 2, cA, sxA, syA, szA);
                 if (!fetch_mu(s + 1)) return;
+                if (s + 2 < ns) spec_issue(s + 2);
                 if (s + 1 >= ns - 2) GS_STAMP(s + 1 == ns - 1 ? 4 : 2);
                 tile_product(cB, sxB, syB, szB, false);
                 if (s + 1 >= ns - 2) GS_STAMP(s + 1 == ns - 1 ? 5 : 3);
                 last_forward = false;
+                if (s + 3 < ns) load_tile(s + 3, cB, sxB, syB, szB);
             }
         }
     }
@@ -429,7 +451,28 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
     // (+14 %), v_readlane broadcasts instead of uniform LDS reads (+12 %), a rehearsal pass to warm the instruction
     // cache (+17 %).  Fewer stages need the neighbour product and the inverse folded into one cached matrix
     // (M_t D T(t,t-1), 295 KB per block): not done.
+    // per-atom operands of the final steps: thread (component q = tid / 64 of atom i = tid % 64), tid < 192
+    // (requested here, after the source loop, to keep them out of its register budget; they land in the slack)
+    double f_al = 0.0, f_es = 0.0, f_yu = 0.0;
+    if (tid < 192) {
+        const int k = 64 * t + lane;
+        f_al = p.alpha[k];
+        f_es = p.es[3 * k + w];
+        f_yu = p.y[3 * k + w];
+    }
     double f_v = 0.0;
+    // This wave's share of the inverse, LDS -> registers, BEFORE the hand-off arrives: 18 sixteen-byte reads per lane
+    // are 147 KB through the CU's one LDS pipeline, which is slack here and critical path later (-7 % per sweep).
+    // (The registers are free now: the source loop's buffers are dead.)
+    double2 mm[18];
+    {
+        const double2 *mp = reinterpret_cast<const double2 *>(sM) + (size_t)(w * 18) * 64 + lane;
+#pragma unroll
+        for (int f2 = 0; f2 < 18; ++f2) mm[f2] = mp[f2 * 64];
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the reads are done before the poll below starts
+#pragma unroll
+        for (int f2 = 0; f2 < 18; ++f2) asm volatile("" : "+v"(mm[f2].x), "+v"(mm[f2].y));  // (keeps them in registers)
+    }
     {
     GS_STAMP(6);
     if (t >= 1) {
@@ -445,6 +488,13 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
             if (!ok) s_ok = 0;
         }
         GS_STAMP(7);
+        if (p.ablate & 8) {  // republish what was polled (+1), nothing else
+            if (lane < 24) {
+                const int j = w + 8 * (lane / 3), q = lane % 3;
+                st_agent(p.mu_new + 192 * (size_t)t + 64 * q + j, wsm[lane] + 1.0);
+            }
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const double bx_ = wsm[3 * k], by_ = wsm[3 * k + 1], bz_ = wsm[3 * k + 2];  // wave-uniform: broadcast reads
@@ -470,10 +520,6 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
     GS_STAMP(9);
     // M_t v_t: wave w takes the column groups g = w, w + 8, w + 16, w + 24 of the folded inverse
     {
-        double2 mm[18];
-        const double2 *mp = reinterpret_cast<const double2 *>(sM) + (size_t)(w * 18) * 64 + lane;
-#pragma unroll
-        for (int f2 = 0; f2 < 18; ++f2) mm[f2] = mp[f2 * 64];
         double a1x = 0.0, a1y = 0.0, a1z = 0.0, a2x = 0.0, a2y = 0.0, a2z = 0.0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
