@@ -168,12 +168,21 @@ int mpmc_hip_update_atoms(mpmc_hip_ctx *ctx, int first, int count, const double 
  * slots at the end -- and that slot range is what later update_atoms / remove_molecule calls and the
  * per-atom downloads (which span mpmc_hip_slot_count() slots, holes reading as zeros) refer to.
  * `mass` = atomic masses (the molecular mass is their sum), `frozen` applies to the whole molecule.
- * Return 0 = done; 1 = cannot be done incrementally (context full, more than 16 atoms, Gauss-Seidel
- * solver modes, incremental options off): upload the whole configuration again; < 0 = error. */
+ * Return 0 = done; 1 = cannot be done incrementally (context full, more than 16 atoms, Gauss-Seidel on the
+ * expanded matrix (persistent_gs = 0), incremental options off): upload the whole configuration again; < 0 = error.
+ * In Gauss-Seidel modes follow up with mpmc_hip_set_sweep_order(). */
 int mpmc_hip_insert_molecule(mpmc_hip_ctx *ctx, int count, const double *x, const double *y, const double *z,
                              const double *charge, const double *polarizability, const double *epsilon,
                              const double *sigma, const double *mass, int frozen, int *first_slot);
 int mpmc_hip_remove_molecule(mpmc_hip_ctx *ctx, int first_slot, int count);
+/* Gauss-Seidel modes (polar_gs / polar_gs_ranked) only: their result depends on the ORDER in which the atoms are
+ * swept -- the order of the reference's atom_array (the molecule lists), which thole_iterative.c walks and
+ * update_ranking() re-sorts stably -- and after insert / remove the engine's slot order is no longer that order.
+ * The caller states it: slots[k] = device slot of the k-th POLARIZABLE atom (polarizability != 0) in its own atom
+ * order.  Required after every insert_molecule / remove_molecule before the next energy() (which fails otherwise);
+ * accepted and ignored in the other solver modes.  Replaces the reference's rebuild of atom_array
+ * (pairs.c:388-547) for this purpose. */
+int mpmc_hip_set_sweep_order(mpmc_hip_ctx *ctx, int count, const int *slots);
 int mpmc_hip_slot_count(mpmc_hip_ctx *ctx);
 
 /* One full energy() evaluation on the device. */

@@ -260,6 +260,10 @@ struct mpmc_hip_ctx {
     unsigned int *d_rankcnt = nullptr;    // neighbour counters of the ranking metric
     std::vector<int> perm_sorted;         // the walk d_rank_used gives (all atoms, as ranked_array)
     bool rank_used_valid = false;
+    // Gauss-Seidel + grand-canonical edits: the sweep ORDER is part of the result, and after insert / remove the
+    // engine's slot order is no longer the caller's atom order.  The caller then states the order of the polarizable
+    // sites (mpmc_hip_set_sweep_order); until it has, energy() refuses to run.
+    bool order_stale = false;
     bool force_host_rank = false;         // this call: no speculation
     bool call_spec_rank = false;          // the call in flight was enqueued speculatively
     int opt_spec_rank = 1;
@@ -809,6 +813,7 @@ extern "C" int mpmc_hip_upload(mpmc_hip_ctx *c, int n, const double *x, const do
     c->view[0].C_valid = c->view[1].C_valid = false;
     c->view[0].pos_valid = c->view[1].pos_valid = false;
     c->rank_used_valid = false;
+    c->order_stale = false;
     ++c->config_rev;
     if (v0.nv > 0) HIPCHK(hipMemcpy(v0.d_idx, v0.h_idx.data(), v0.nv * sizeof(int), hipMemcpyHostToDevice));
     return 0;
@@ -906,10 +911,17 @@ extern "C" int mpmc_hip_update_atoms(mpmc_hip_ctx *c, int first, int count, cons
 // Return value 1 = not possible incrementally (context full, molecule too large, a solver mode that
 // keeps ordered data): the caller uploads the whole configuration again.
 // ---------------------------------------------------------------------------------------------
+static bool gs_order_mode(const mpmc_hip_ctx *c) {  // Gauss-Seidel on the chain kernel: the view order is the caller's
+    const mpmc_hip_params &P = c->par;
+    return !P.rd_only && P.polarization && !P.polar_zodid && (P.polar_gs || P.polar_gs_ranked) && c->opt_pair_coef != 0 &&
+           c->opt_persistent_gs != 0;
+}
+
 static bool edits_supported(const mpmc_hip_ctx *c) {
     const mpmc_hip_params &P = c->par;
     if (!c->have_atoms || c->all_dirty || !c->opt_incremental || !c->opt_incremental_pairs || !c->opt_pair_coef) return false;
-    if (!P.rd_only && P.polarization && (P.polar_gs || P.polar_gs_ranked)) return false;
+    // Gauss-Seidel: only with the chain kernel, whose view is rebuilt from the order the caller states afterwards
+    if (!P.rd_only && P.polarization && (P.polar_gs || P.polar_gs_ranked) && !gs_order_mode(c)) return false;
     return true;
 }
 
@@ -947,6 +959,7 @@ static void mark_edited(mpmc_hip_ctx *c, int first, int count) {
     if ((int)c->dirty_atoms.size() > 4 * kMaxDirty) c->all_dirty = true;
     c->have_polar_result = false;
     c->self_valid = false;
+    c->rank_used_valid = false;  // (polar_gs_ranked: the next call sorts the metric on the host)
     ++c->config_rev;
 }
 
@@ -967,7 +980,9 @@ extern "C" int mpmc_hip_remove_molecule(mpmc_hip_ctx *c, int first, int count) {
     ed.n = count;
     for (int i = 0; i < count; ++i) {
         ed.idx[i] = first + i;
-        ed.vslot[i] = v0.slot_of_atom[first + i];  // the view slot stays with the atom slot, as a hole
+        // the view slot stays with the atom slot, as a hole -- except in Gauss-Seidel modes, where the view is rebuilt
+        // from the caller's order (mpmc_hip_set_sweep_order) and is not patched here
+        ed.vslot[i] = gs_order_mode(c) ? -1 : v0.slot_of_atom[first + i];
         ed.mol[i] = -2 - (first + i);
         ed.flags[i] = 0;
         c->slot_valid[first + i] = 0;
@@ -976,6 +991,11 @@ extern "C" int mpmc_hip_remove_molecule(mpmc_hip_ctx *c, int first, int count) {
     c->holes.push_back(std::make_pair(first, count));
     c->n_valid -= count;
     mark_edited(c, first, count);
+    if (gs_order_mode(c)) {
+        c->order_stale = true;
+        v0.pos_valid = false;
+        v0.C_valid = false;
+    }
     return 0;
 }
 
@@ -1003,9 +1023,10 @@ extern "C" int mpmc_hip_insert_molecule(mpmc_hip_ctx *c, int count, const double
         first = c->n;
     }
     // view slots for the polarizable sites: the atom slot's old one if it has one, else appended
+    const bool gs_mode = gs_order_mode(c);
     int new_view = 0;
     for (int i = 0; i < count; ++i) {
-        const bool had = first + i < (int)v0.slot_of_atom.size() && v0.slot_of_atom[first + i] >= 0;
+        const bool had = !gs_mode && first + i < (int)v0.slot_of_atom.size() && v0.slot_of_atom[first + i] >= 0;
         if (polarizability[i] != 0.0 && !had) ++new_view;
     }
     if (v0.nv + new_view > v0.cap) return 1;
@@ -1032,8 +1053,8 @@ extern "C" int mpmc_hip_insert_molecule(mpmc_hip_ctx *c, int count, const double
     ed.n = count;
     for (int i = 0; i < count; ++i) {
         const int a = first + i;
-        int s = v0.slot_of_atom[a];
-        if (polarizability[i] != 0.0 && s < 0) {
+        int s = gs_mode ? -1 : v0.slot_of_atom[a];
+        if (!gs_mode && polarizability[i] != 0.0 && s < 0) {
             s = v0.nv++;
             v0.slot_of_atom[a] = s;
             v0.h_idx.resize(v0.nv);
@@ -1061,7 +1082,51 @@ extern "C" int mpmc_hip_insert_molecule(mpmc_hip_ctx *c, int count, const double
     if (launch_edits(c, ed)) return -1;
     c->n_valid += count;
     mark_edited(c, first, count);
+    if (gs_mode) {  // the view is rebuilt from the order the caller states next
+        c->order_stale = true;
+        v0.pos_valid = false;
+        v0.C_valid = false;
+    }
     *first_slot = first;
+    return 0;
+}
+
+// Gauss-Seidel modes after insert / remove: the polarizable sites in the CALLER's atom order (the order of the
+// reference's atom_array, which thole_iterative.c walks and update_ranking() stably re-sorts), as device slots.
+// Ignored (0) in the other solver modes, whose result does not depend on an order.
+extern "C" int mpmc_hip_set_sweep_order(mpmc_hip_ctx *c, int count, const int *slots) {
+    if (!c || !c->have_atoms) return fail("MPMC_HIP: set_sweep_order: no configuration uploaded");
+    if (c->in_flight) return fail("MPMC_HIP: set_sweep_order between energy_begin() and energy_end()");
+    if (!gs_order_mode(c)) return 0;
+    SweepView &v0 = c->view[0];
+    if (count < 0 || count > v0.cap || (count > 0 && !slots)) return fail("MPMC_HIP: set_sweep_order: bad arguments");
+    std::vector<char> seen(c->n, 0);
+    for (int k = 0; k < count; ++k) {
+        const int a = slots[k];
+        if (a < 0 || a >= c->n || !c->slot_valid[a] || seen[a])
+            return fail("MPMC_HIP: set_sweep_order: entry %d (slot %d) is not a distinct atom of the configuration", k, a);
+        seen[a] = 1;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    if (flush_moves(c)) return -1;  // queued moves were addressed through the old view
+    v0.h_idx.assign(slots, slots + count);
+    v0.nv = count;
+    v0.nvpad = std::max(128, round_up(count, 128));
+    v0.slot_of_atom.assign(c->n, -1);
+    std::vector<int> hs(c->max_npad, -1);
+    for (int k = 0; k < count; ++k) {
+        v0.slot_of_atom[slots[k]] = k;
+        hs[slots[k]] = k;
+    }
+    HIPCHK(hipMemcpy(v0.d_slot, hs.data(), hs.size() * sizeof(int), hipMemcpyHostToDevice));
+    if (count > 0) HIPCHK(hipMemcpy(v0.d_idx, slots, count * sizeof(int), hipMemcpyHostToDevice));
+    v0.pos_valid = false;
+    v0.C_valid = v0.A_valid = false;
+    c->view[1].C_valid = c->view[1].A_valid = false;
+    c->rank_used_valid = false;
+    c->order_stale = false;
+    c->have_polar_result = false;
+    ++c->config_rev;
     return 0;
 }
 
@@ -1582,6 +1647,9 @@ extern "C" int mpmc_hip_energy_begin(mpmc_hip_ctx *c) {
     if (c->in_flight) return fail("MPMC_HIP: energy_begin: the previous evaluation has not been collected");
     if (!c->have_atoms) return fail("MPMC_HIP: energy: no configuration uploaded");
     if (!c->have_box) return fail("MPMC_HIP: energy: no box set");
+    if (c->order_stale && gs_order_mode(c))
+        return fail("MPMC_HIP: energy: Gauss-Seidel after insert_molecule / remove_molecule needs the sweep order of the "
+                    "new configuration (mpmc_hip_set_sweep_order)");
     HIPCHK(hipSetDevice(c->device));
     const mpmc_hip_params &P = c->par;
     c->ewald_alpha = P.ewald_alpha_set ? P.ewald_alpha : 3.5 / c->cutoff;                    // pbc.c:73-74

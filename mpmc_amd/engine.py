@@ -16,7 +16,7 @@ EXPORTS = [
     "mpmc_hip_last_error", "mpmc_hip_abi_version", "mpmc_hip_device_count", "mpmc_hip_create",
     "mpmc_hip_destroy", "mpmc_hip_set_option", "mpmc_hip_default_params", "mpmc_hip_set_params", "mpmc_hip_set_box",
     "mpmc_hip_upload", "mpmc_hip_update_atoms", "mpmc_hip_insert_molecule", "mpmc_hip_remove_molecule",
-    "mpmc_hip_slot_count", "mpmc_hip_energy", "mpmc_hip_energy_begin", "mpmc_hip_energy_end",
+    "mpmc_hip_slot_count", "mpmc_hip_set_sweep_order", "mpmc_hip_energy", "mpmc_hip_energy_begin", "mpmc_hip_energy_end",
     "mpmc_hip_download_dipoles",
     "mpmc_hip_download_amatrix", "mpmc_hip_download_ranking", "mpmc_hip_get_timings",
     "mpmc_hip_comm_unique_id", "mpmc_hip_comm_create", "mpmc_hip_comm_size", "mpmc_hip_comm_rank",
@@ -129,6 +129,7 @@ def load():
     lib.mpmc_hip_insert_molecule.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.POINTER(C.c_int)]
     lib.mpmc_hip_remove_molecule.argtypes = [vp, C.c_int, C.c_int]
     lib.mpmc_hip_slot_count.argtypes = [vp]
+    lib.mpmc_hip_set_sweep_order.argtypes = [vp, C.c_int, vp]
     lib.mpmc_hip_energy.argtypes = [vp, C.POINTER(Result)]
     lib.mpmc_hip_energy_begin.argtypes = [vp]
     lib.mpmc_hip_energy_end.argtypes = [vp, C.POINTER(Result)]
@@ -246,6 +247,11 @@ class Engine:
         if rc < 0:
             _chk(rc)
         return rc == 0
+
+    def set_sweep_order(self, slots):
+        """Gauss-Seidel modes after insert / remove: device slots of the polarizable atoms in the caller's atom order."""
+        a = np.ascontiguousarray(slots, dtype=np.int32)
+        _chk(self.lib.mpmc_hip_set_sweep_order(self.ctx, len(a), a.ctypes.data))
 
     def energy(self):
         r = Result()

@@ -271,6 +271,7 @@ static int sync_device(system_t *system) {
         natoms += sync_molecule(system, sh, m, &rc);
         if (rc) return rc;
     }
+    int list_changed = 0;
     /* removals first, so that an insertion of the same size can take the slots */
     for (int f = 0; f < sh->nfirst;) {
         const int s = sh->first[f];
@@ -283,6 +284,7 @@ static int sync_device(system_t *system) {
         if (rc > 0) return 1;
         sh->ticket[s] = 0;
         sh->first[f] = sh->first[--sh->nfirst];
+        list_changed = 1;
     }
     for (int f = 0; f < nfresh; f++) {
         molecule_t *m = fresh[f];
@@ -306,6 +308,21 @@ static int sync_device(system_t *system) {
         sh->count[s] = k;
         sh->seen[s] = sh->epoch;
         sh->first[sh->nfirst++] = s;
+        list_changed = 1;
+    }
+    if (list_changed && system->polarization && (system->polar_gs || system->polar_gs_ranked)) {
+        /* Gauss-Seidel sweeps walk the atoms in list order (the reference's atom_array, thole_iterative.c:27-59), and the
+         * device slots no longer follow the lists: state the order of the polarizable sites (one walk, N ints) */
+        int *order = malloc((natoms > 0 ? natoms : 1) * sizeof(int));
+        int k = 0;
+        for (molecule_t *m = system->molecules; m; m = m->next) {
+            int i = m->hip_slot;
+            for (atom_t *a = m->atoms; a; a = a->next, i++)
+                if (a->polarizability != 0.0) order[k++] = i;
+        }
+        const int rc = mpmc_hip_set_sweep_order(ctx, k, order);
+        free(order);
+        if (rc) return hip_fail("set_sweep_order");
     }
     system->natoms = natoms;
     system->hip_uploaded_natoms = natoms;

@@ -164,6 +164,41 @@ def test_uvt_incremental_edits_match_full_reuploads():
         h.close()
 
 
+def test_uvt_gauss_seidel_edits_follow_the_list_order():
+    """Grand-canonical chain under the reference's production flags (ranked Gauss-Seidel: the sweep ORDER is part of
+    the result).  Insertions and removals edit the resident configuration and the host states the new list order of
+    the polarizable sites (mpmc_hip_set_sweep_order); the same chain with edits disabled re-uploads the whole
+    configuration in list order at every change of N.  Same decisions, same atom counts, energies equal to rounding,
+    and the configuration the chain ends on matches the oracle -- which sweeps in list order like the reference."""
+    s = synth.s_pol(160, spacing=4.5)
+    p = dict(synth.FLAGS_POL_PRODUCTION)
+    chains, trace = [], [[], []]
+    for k, incremental in enumerate((1, 0)):
+        h = host.HostSystem(s, p, seed=33, move_factor=0.05, rot_factor=0.05,
+                            extra={"ensemble": "uvt", "insert_probability": 0.7, "pressure": 300.0})
+        h.energy()  # creates the context
+        h.set_option("incremental_amatrix", incremental)  # 0: the engine asks for re-uploads instead of edits
+        for _ in range(12):
+            acc = h.mc_steps(8)
+            trace[k].append((acc, h.natoms(), h.observables()["energy"]))
+        chains.append(h)
+    ns = {t[1] for t in trace[0]}
+    assert len(ns) > 2, "N hardly changed"
+    for a, b in zip(*trace):
+        assert a[0] == b[0] and a[1] == b[1]
+        assert abs(a[2] - b[2]) <= 1e-10 * max(1.0, abs(b[2]))
+    for h in chains:
+        final = h.system(s["basis"])
+        want = oracle.energy(final, p, want_vectors=True)
+        e = h.energy()  # the device may still hold a rejected trial: evaluate the configuration the chain kept
+        assert abs(e - want["energy"]) < 1e-9 * max(1.0, abs(want["energy"]))
+        o = h.observables()
+        assert abs(o["polarization_energy"] - want["polarization_energy"]) < 1e-9 * max(1e-3, abs(want["polarization_energy"]))
+        d = h.dipoles()
+        assert np.abs(d["mu"] - want["mu"]).max() <= 1e-9 * np.abs(want["mu"]).max()
+        h.close()
+
+
 def test_uvt_chain_without_polarization():
     """Grand-canonical chain of charged LJ dimers (no polarization): insertions / removals only touch the pair
     tiles, the reciprocal-space block partials, the long-range-correction tiles and the cached self term."""

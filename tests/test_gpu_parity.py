@@ -477,6 +477,48 @@ def test_ranked_walk_is_speculated_and_repeated_when_the_metric_changes():
         e.close()
 
 
+def test_gauss_seidel_after_an_insertion_needs_and_follows_the_stated_order():
+    """In Gauss-Seidel modes the sweep order is part of the result.  After mpmc_hip_insert_molecule the engine's slot
+    order is not the caller's atom order any more: energy() must refuse to run until mpmc_hip_set_sweep_order() has
+    stated it, and with the order stated the result must be that of a fresh upload in that atom order (the reference
+    inserts a molecule IN FRONT of the one it was copied from, mc_moves.c:583-640)."""
+    s = synth.s_pol(320)
+    p = dict(synth.FLAGS_POL_PRODUCTION)
+    eng = engine.Engine(320 + 64)
+    eng.load_system(s, p)
+    eng.energy()
+    sl = slice(35, 40)  # a copy of molecule 7, displaced to a gap in the lattice
+    newpos = s["pos"][sl] + np.array([1.7, 1.9, -1.6])
+    first = eng.insert_molecule(newpos, s["charge"][sl], s["alpha"][sl], s["epsilon"][sl], s["sigma"][sl], s["mass"][sl])
+    assert first == 320
+    with pytest.raises(engine.EngineError, match="set_sweep_order"):
+        eng.energy()
+    # the caller's atom order: the new molecule sits in front of molecule 7 (atoms 35..39)
+    order_atoms = np.r_[np.arange(0, 35), np.arange(320, 325), np.arange(35, 320)]
+    alpha_by_slot = np.r_[s["alpha"], s["alpha"][sl]]
+    eng.set_sweep_order([a for a in order_atoms if alpha_by_slot[a] != 0.0])
+    got = eng.energy()
+    s2 = {}
+    for k, v in s.items():
+        if k == "basis":
+            s2[k] = v
+        elif k == "pos":
+            s2[k] = np.concatenate([v[:35], newpos, v[35:]])
+        elif k == "molecule":
+            s2[k] = np.concatenate([v[:35], np.full(5, 10 ** 6, dtype=v.dtype), v[35:]])
+        else:
+            s2[k] = np.concatenate([v[:35], v[sl], v[35:]])
+    want = oracle.energy(s2, p)
+    check_energies(got, want)
+    fresh = run_engine(s2, p)
+    assert rel(got["polarization_energy"], fresh["polarization_energy"]) < 1e-11
+    # stating the plain slot order instead gives a DIFFERENT (wrong) Gauss-Seidel result: the order matters
+    eng.set_sweep_order([a for a in range(325) if alpha_by_slot[a] != 0.0])
+    other = eng.energy()
+    assert rel(other["polarization_energy"], want["polarization_energy"]) > 1e-9
+    eng.close()
+
+
 def test_gauss_seidel_hand_off_timeout_is_sticky_and_reported():
     """A hand-off that never arrives in sweep 1 of 4 must surface as an error of energy() -- not be erased by the
     arming step of the later sweeps, and not come back as a non-finite energy the host would take for a rejected
