@@ -129,6 +129,8 @@ struct SweepView {
     unsigned long long C_epoch = 0;   // bumped by every full build of C
     unsigned long long M_epoch = 0;   // C_epoch the chain data were last fully built under (0: never)
     unsigned long long M_call = 0;    // energy() call that last maintained them
+    int rebuild_from = -1;            // >= 0: the view's order changed from this 64-atom block on (set_sweep_order):
+                                      // blocks in front of it keep their data, the rest is rebuilt at the next energy()
     double *Srow = nullptr, *Zcol = nullptr;  // partial sums of the symmetric sweep
     size_t symcap = 0;
     std::vector<int> h_idx;
@@ -814,6 +816,7 @@ extern "C" int mpmc_hip_upload(mpmc_hip_ctx *c, int n, const double *x, const do
     c->view[0].pos_valid = c->view[1].pos_valid = false;
     c->rank_used_valid = false;
     c->order_stale = false;
+    c->view[0].rebuild_from = c->view[1].rebuild_from = -1;
     ++c->config_rev;
     if (v0.nv > 0) HIPCHK(hipMemcpy(v0.d_idx, v0.h_idx.data(), v0.nv * sizeof(int), hipMemcpyHostToDevice));
     return 0;
@@ -992,9 +995,8 @@ extern "C" int mpmc_hip_remove_molecule(mpmc_hip_ctx *c, int first, int count) {
     c->n_valid -= count;
     mark_edited(c, first, count);
     if (gs_order_mode(c)) {
-        c->order_stale = true;
+        c->order_stale = true;  // (the view's data are reconciled by set_sweep_order + the next energy())
         v0.pos_valid = false;
-        v0.C_valid = false;
     }
     return 0;
 }
@@ -1085,7 +1087,6 @@ extern "C" int mpmc_hip_insert_molecule(mpmc_hip_ctx *c, int count, const double
     if (gs_mode) {  // the view is rebuilt from the order the caller states next
         c->order_stale = true;
         v0.pos_valid = false;
-        v0.C_valid = false;
     }
     *first_slot = first;
     return 0;
@@ -1109,6 +1110,13 @@ extern "C" int mpmc_hip_set_sweep_order(mpmc_hip_ctx *c, int count, const int *s
     }
     HIPCHK(hipSetDevice(c->device));
     if (flush_moves(c)) return -1;  // queued moves were addressed through the old view
+    // how far the new order agrees with the old one: the blocks in front of the first difference keep their data
+    int p0 = 0;
+    {
+        const int m = std::min((int)v0.h_idx.size(), count);
+        while (p0 < m && v0.h_idx[p0] == slots[p0]) ++p0;
+    }
+    const bool keep_prefix = v0.C_valid && v0.rebuild_from < 0 && v0.M_epoch == v0.C_epoch && v0.M_call == c->energy_calls;
     v0.h_idx.assign(slots, slots + count);
     v0.nv = count;
     v0.nvpad = std::max(128, round_up(count, 128));
@@ -1121,7 +1129,14 @@ extern "C" int mpmc_hip_set_sweep_order(mpmc_hip_ctx *c, int count, const int *s
     HIPCHK(hipMemcpy(v0.d_slot, hs.data(), hs.size() * sizeof(int), hipMemcpyHostToDevice));
     if (count > 0) HIPCHK(hipMemcpy(v0.d_idx, slots, count * sizeof(int), hipMemcpyHostToDevice));
     v0.pos_valid = false;
-    v0.C_valid = v0.A_valid = false;
+    if (keep_prefix) {
+        v0.rebuild_from = p0 / 64;  // (C stays "valid": setup_view rebuilds the tail and updates moved atoms' entries)
+        v0.C_valid = true;
+    } else {
+        v0.rebuild_from = -1;
+        v0.C_valid = false;
+    }
+    v0.A_valid = false;
     c->view[1].C_valid = c->view[1].A_valid = false;
     c->rank_used_valid = false;
     c->order_stale = false;

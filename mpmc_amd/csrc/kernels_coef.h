@@ -93,10 +93,12 @@ __device__ __forceinline__ double2 stream_load_coef(const double2 *p) {
 // grid = (nt [tj], nt [ti]); block = 256 (wave w fills steps 16 w .. 16 w + 15); tiles below the
 // diagonal exit.  `a` is the view's atom set (coordinates / flags in slot order).
 // ---------------------------------------------------------------------------------------------
+// (tj_min > 0: only the tiles whose column block is >= tj_min -- the tail of a view whose order changed from that
+// block on; the tiles in front of it involve unchanged atoms only)
 __global__ __launch_bounds__(64 * kCoefWaves) void build_coef_kernel(DevAtoms a, DevBox bx, double damp, int ntld,
-                                                                       double2 *__restrict__ C) {
+                                                                       double2 *__restrict__ C, int tj_min) {
     const int tj = blockIdx.x, ti = blockIdx.y;
-    if (tj < ti) return;
+    if (tj < ti || tj < tj_min) return;
     const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
     __shared__ double sx[64], sy[64], sz[64];
     __shared__ int sv[64];

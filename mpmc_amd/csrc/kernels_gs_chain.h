@@ -164,9 +164,10 @@ __device__ __forceinline__ double wave_rotate_up(double v) {
 // Expanded tensors of the sub-diagonal tiles (t, t-1), t = blk[b] (or every t >= 1 with nsel = 0).
 // grid = nsel or nb - 1; block = 256.  A tile is a pure function of its two blocks' coordinates.
 // ---------------------------------------------------------------------------------------------
+constexpr int kMaxBlockList = 48;
 struct BlockList {
     int n;
-    int blk[48];
+    int blk[kMaxBlockList];
 };
 
 template <int ORTHO>
@@ -196,18 +197,21 @@ __global__ __launch_bounds__(256) void gs_neighbor_tensor_kernel(const double2 *
 
 // ---------------------------------------------------------------------------------------------
 // M_t = (I + D L)^-1 of block t = blk[blockIdx.y] (or blockIdx.y with nsel = 0): forward substitution on the
-// identity, right-looking.  Columns are independent, so a block is spread over 48 workgroups of 4 waves (one wave
-// per SIMD, one scalar column per wave): lane a accumulates r_a = sum_{b<a} T_ab x_b; at step b the finished
+// identity, right-looking.  Columns are independent, so a block is spread over 12 workgroups of 16 waves (one scalar
+// column per wave; every workgroup first expands the block's tensors from the 64-KB diagonal coefficient tile, which
+// at ~10 us through one CU is most of its run time -- 48 workgroups of 4 waves repeated that load four times as
+// often and made a full rebuild 166 us): lane a accumulates r_a = sum_{b<a} T_ab x_b; at step b the finished
 // x_b = -alpha_b r_b leaves lane b through SGPRs (v_readlane, no LDS crossbar, no reduction) and every lane a > b
 // adds T_ab x_b.  The block's tensors are expanded once into LDS from the diagonal coefficient tile (packed by
 // column: rows a > b of column b are contiguous, 6 doubles per pair).
-// grid = (48, nsel or nb); block = 256; dynamic LDS = kInverseLds.
+// grid = (12, nsel or nb); block = 1024; dynamic LDS = kInverseLds.
 // ---------------------------------------------------------------------------------------------
 constexpr int kInverseLds = (kGsPairs * 6 + 4 * 64) * 8;
-constexpr int kInverseGroups = 48;
+constexpr int kInverseGroups = 12;
+constexpr int kInverseThreads = 1024;
 
 template <int ORTHO>
-__global__ __launch_bounds__(256) void gs_block_inverse_kernel(const double2 *__restrict__ C, int ntld,
+__global__ __launch_bounds__(kInverseThreads) void gs_block_inverse_kernel(const double2 *__restrict__ C, int ntld,
                                                                 const double *__restrict__ px,
                                                                 const double *__restrict__ py,
                                                                 const double *__restrict__ pz,
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(256) void gs_block_inverse_kernel(const double2 *__
     __syncthreads();
     // expand the strictly lower triangle: pair (a, b), a > b, is element (l = b, s = a - b) of the diagonal tile
     const double2 *tile = C + coef_tile_index(t, t, ntld) * (kCoefTile * kCoefTile);
-    for (int s = 1 + w; s < 64; s += 4) {
+    for (int s = 1 + w; s < 64; s += kInverseThreads / 64) {
         const int b = lane, a = lane + s;
         if (a < 64) {
             const double2 c = tile[s * 64 + b];
@@ -246,7 +250,7 @@ __global__ __launch_bounds__(256) void gs_block_inverse_kernel(const double2 *__
         }
     }
     __syncthreads();
-    const int colidx = 4 * blockIdx.x + w;   // this wave's scalar column of M: atom c, component q
+    const int colidx = (kInverseThreads / 64) * blockIdx.x + w;   // this wave's scalar column of M: atom c, component q
     const int c = colidx / 3, q = colidx % 3;
     const double al = sal[lane];
     double r0 = 0.0, r1 = 0.0, r2 = 0.0;     // lane a: sum_{c <= b < a} T_ab x_b
