@@ -268,6 +268,7 @@ struct mpmc_hip_ctx {
     bool order_stale = false;
     bool force_host_rank = false;         // this call: no speculation
     bool call_spec_rank = false;          // the call in flight was enqueued speculatively
+    bool rank_on_side = false;            // this call: metric computed and copied to the host on the side stream
     int opt_spec_rank = 1;
     unsigned long long spec_redos = 0;
     hipEvent_t ev_rank = nullptr;
