@@ -348,12 +348,13 @@ def main():
         ch.energy()  # creates the device context, uploads the configuration
     # ---- walker pooling through the C ABI: rank 0 makes the RCCL id, the launcher's process group hands it round
     rccl_ranks = 1
-    if world > 1:
+    pooled = dist is not None  # under a launcher the collective runs also with one rank (same code path as N ranks)
+    if pooled:
         ids = [host.walkers_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         chain.walkers_init(world, rank, ids[0])
         rccl_ranks = world
-    avg = WalkerAverages(reducer=AbiReducer(chain) if world > 1 else None)
+    avg = WalkerAverages(reducer=AbiReducer(chain) if pooled else None)
 
     for var, opt in (("MPMC_OVERLAP", "overlap_streams"), ("MPMC_SIDE_AFTER", "side_after"),
                      ("MPMC_STEP_GRAPH", "step_graph"), ("MPMC_SYM_MODE", "sym_mode"), ("MPMC_GS_DEBUG", "persistent_gs")):
@@ -518,7 +519,8 @@ def main():
                                     "; energy() incremental (bit-identical to full)"),
                        "n_atoms": n, "n_polarizable": n_pol, "walkers": world * W, "corrtime": args.corrtime,
                        "parallelism": "%d independent walkers, %d per GPU" % (world * W, W),
-                       "collective": "mpmc_hip_allreduce_observables_begin/_end (C ABI, RCCL) every corrtime",
+                       "collective": ("mpmc_hip_allreduce_observables_begin/_end (C ABI, RCCL) every corrtime" if pooled
+                                      else "none (single walker, no launcher)"),
                        "rccl_ranks": rccl_ranks},
             "full_rebuild_steps_per_s": full_rebuild_rate,
             "roofline": {"kernel": kernel_name + " (Thole field / dipole sweep)", "bound": "hbm",

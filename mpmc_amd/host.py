@@ -151,7 +151,7 @@ class HostSystem:
 
     # ---- walker pooling through the C ABI's RCCL entry (the reference's MPI_Gather, mc.c:417-432)
     def walkers_init(self, nranks, rank, unique_id):
-        buf = (C.c_ubyte * 128).from_buffer_copy(bytes(unique_id))
+        buf = (C.c_ubyte * 128).from_buffer_copy(bytes(unique_id)) if unique_id is not None else None
         if self.lib.walkers_init(self.ptr, int(nranks), int(rank), buf) != 0:
             raise engine.EngineError("walkers_init: " + engine.load().mpmc_hip_last_error().decode())
 

@@ -368,7 +368,7 @@ int walkers_init(system_t *system, int nranks, int rank, const unsigned char id[
     if (nranks < 1 || rank < 0 || rank >= nranks) return -1;
     system->walker_rank = rank;
     system->walker_nranks = nranks;
-    if (nranks == 1) return 0; /* nothing to pool with */
+    if (nranks == 1 && !id) return 0; /* nothing to pool with (with an id a 1-rank communicator is made: same code path) */
     if (!system->hip_ctx) {
         error("MC: walkers_init needs the device context (call energy() first)\n");
         return -1;

@@ -33,6 +33,27 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
         assert d["valu_kernels"][k]["pairs_per_s"] > 1e9
 
 
+def test_bench_under_a_launcher_pools_through_the_c_abi_collective_with_one_rank():
+    """Under `torch.distributed.run` the walker pooling goes through the C ABI's RCCL entry also with ONE rank: the
+    unique id is made by rank 0 and handed round by the launcher's process group, the communicator is created on the
+    engine's device beside torch's own RCCL, and every corrtime an all-reduce is started and collected.  (Two ranks
+    need two GPUs: next test.)"""
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "1", "--steps", "40", "--warmup", "5", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["config"]["rccl_ranks"] == 1 and "RCCL" in d["config"]["collective"]
+    assert d["walker_averages"]["samples"] == 5 and d["value"] > 10.0
+
+
 def test_two_walkers_pool_through_the_c_abi_collective():
     """configs[4] in small: `bench.py --gpus 2` starts its two ranks itself, each walker on its own GPU, observables
     pooled by mpmc_hip_allreduce_observables_begin/_end (RCCL).  Needs two GPUs: skipped on the one-GPU box."""
