@@ -515,6 +515,32 @@ def test_gauss_seidel_after_an_insertion_needs_and_follows_the_stated_order():
     eng.close()
 
 
+def test_degenerate_sweep_views():
+    """Edges of the sweep view: polarization switched on with no polarizable site at all (an empty view), a single
+    atom, and views that end exactly on / just past a 64-site block boundary -- Jacobi, ranked Gauss-Seidel and the
+    precision stopping rule."""
+    s = synth.s_lj(64)  # alpha = 0 everywhere
+    for flags in (dict(polar_max_iter=4), dict(polar_max_iter=4, polar_gs_ranked=1, polar_palmo=1),
+                  dict(polar_max_iter=0, polar_precision=1e-6)):
+        p = dict(temperature=77.0, polarization=1, polar_damp=2.1304)
+        p.update(flags)
+        got, want = run_engine(s, p), oracle.energy(s, p)
+        check_energies(got, want)
+        assert got["polarization_energy"] == 0.0
+    one = {k: (v[:1] if k != "basis" else v) for k, v in synth.s_pol(10).items()}
+    for flags in (dict(polar_max_iter=4), dict(polar_max_iter=3, polar_gs=1)):
+        p = dict(temperature=77.0, polarization=1, polar_damp=2.1304)
+        p.update(flags)
+        check_energies(run_engine(one, p), oracle.energy(one, p))
+    for nmol in (21, 22, 43):  # 63, 66 and 129 polarizable sites
+        sp = synth.s_pol(5 * nmol)
+        p = dict(synth.FLAGS_POL_PRODUCTION)
+        got = run_engine(sp, p, vectors=True)
+        want = oracle.energy(sp, p, want_vectors=True)
+        check_energies(got, want)
+        assert np.abs(got["mu"] - want["mu"]).max() <= 1e-10 * np.abs(want["mu"]).max()
+
+
 def test_gauss_seidel_hand_off_timeout_is_sticky_and_reported():
     """A hand-off that never arrives in sweep 1 of 4 must surface as an error of energy() -- not be erased by the
     arming step of the later sweeps, and not come back as a non-finite energy the host would take for a rejected
