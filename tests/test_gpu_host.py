@@ -45,12 +45,15 @@ def test_host_chain_tracks_the_oracle():
     h.close()
 
 
-def test_interleaved_walkers_take_the_steps_they_would_take_alone():
+@pytest.mark.parametrize("production", [False, True])
+def test_interleaved_walkers_take_the_steps_they_would_take_alone(production):
     """host_mc_steps_multi drives several walkers from one process (their kernels interleave on the device).
     Each walker has its own random-number stream and engine context: its trajectory must be, bit for bit, the
-    one it produces when it runs alone."""
-    s = synth.s_pol(320)
-    p = dict(synth.FLAGS_POL_JACOBI, polar_max_iter=4)
+    one it produces when it runs alone.  With the production flags three persistent Gauss-Seidel chain kernels share
+    the device at once: nothing in them assumes co-residency (a workgroup takes its block from a ticket counter when
+    it starts), so they make progress however the workgroups of the three launches are interleaved."""
+    s = synth.s_pol(640 if production else 320)
+    p = dict(synth.FLAGS_POL_PRODUCTION) if production else dict(synth.FLAGS_POL_JACOBI, polar_max_iter=4)
     seeds = (7, 8, 9)
     alone = []
     for sd in seeds:
