@@ -512,9 +512,13 @@ extern "C" int mpmc_hip_create(mpmc_hip_ctx **out, int device, int max_atoms) {
     for (int o = 0; o < 2; ++o)
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_kernel_of(o)),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, kChainLds));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(gs_block_inverse_kernel<0>),
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(gs_block_inverse_kernel<0, 4>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, kInverseLds));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(gs_block_inverse_kernel<1>),
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(gs_block_inverse_kernel<1, 4>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, kInverseLds));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(gs_block_inverse_kernel<0, 16>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, kInverseLds));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(gs_block_inverse_kernel<1, 16>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, kInverseLds));
     /* Two priority classes, so that the two streams never share a hardware queue whatever other streams
      * the process holds (the runtime pools its queues per priority; with RCCL initialised first both

@@ -204,14 +204,14 @@ __global__ __launch_bounds__(256) void gs_neighbor_tensor_kernel(const double2 *
 // x_b = -alpha_b r_b leaves lane b through SGPRs (v_readlane, no LDS crossbar, no reduction) and every lane a > b
 // adds T_ab x_b.  The block's tensors are expanded once into LDS from the diagonal coefficient tile (packed by
 // column: rows a > b of column b are contiguous, 6 doubles per pair).
-// grid = (12, nsel or nb); block = 1024; dynamic LDS = kInverseLds.
+// grid = (192 / WAVES, nsel or nb); block = 64 WAVES; dynamic LDS = kInverseLds.
 // ---------------------------------------------------------------------------------------------
 constexpr int kInverseLds = (kGsPairs * 6 + 4 * 64) * 8;
-constexpr int kInverseGroups = 12;
-constexpr int kInverseThreads = 1024;
-
-template <int ORTHO>
-__global__ __launch_bounds__(kInverseThreads) void gs_block_inverse_kernel(const double2 *__restrict__ C, int ntld,
+// Two geometries (WAVES waves per workgroup, 192 / WAVES workgroups per block): 4 waves x 48 workgroups finishes a
+// couple of blocks soonest (17.5 vs 24 us: the moved atoms' blocks of view 0 are on the step's critical path), 16 waves
+// x 12 workgroups repeats the tile expansion a quarter as often and rebuilds a whole view 3.6x faster (46 vs 166 us).
+template <int ORTHO, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void gs_block_inverse_kernel(const double2 *__restrict__ C, int ntld,
                                                                 const double *__restrict__ px,
                                                                 const double *__restrict__ py,
                                                                 const double *__restrict__ pz,
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(kInverseThreads) void gs_block_inverse_kernel(const
     __syncthreads();
     // expand the strictly lower triangle: pair (a, b), a > b, is element (l = b, s = a - b) of the diagonal tile
     const double2 *tile = C + coef_tile_index(t, t, ntld) * (kCoefTile * kCoefTile);
-    for (int s = 1 + w; s < 64; s += kInverseThreads / 64) {
+    for (int s = 1 + w; s < 64; s += WAVES) {
         const int b = lane, a = lane + s;
         if (a < 64) {
             const double2 c = tile[s * 64 + b];
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(kInverseThreads) void gs_block_inverse_kernel(const
         }
     }
     __syncthreads();
-    const int colidx = (kInverseThreads / 64) * blockIdx.x + w;   // this wave's scalar column of M: atom c, component q
+    const int colidx = WAVES * blockIdx.x + w;   // this wave's scalar column of M: atom c, component q
     const int c = colidx / 3, q = colidx % 3;
     const double al = sal[lane];
     double r0 = 0.0, r1 = 0.0, r2 = 0.0;     // lane a: sum_{c <= b < a} T_ab x_b
