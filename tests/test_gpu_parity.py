@@ -515,6 +515,35 @@ def test_gauss_seidel_after_an_insertion_needs_and_follows_the_stated_order():
     eng.close()
 
 
+def test_gauss_seidel_chain_at_16384_atoms():
+    """BASELINE's largest size (S-POL(16384): 9830 polarizable sites, 154 blocks, one workgroup each), production
+    flags.  The CPU oracle is out of reach here (a 19 GB matrix); the chain kernel with its cached block inverses is
+    held against the literal forward substitution on the expanded matrix (persistent_gs = 0), and a move followed by
+    its restore must give back the first energy bit for bit (every cached unit is a function of the coordinates)."""
+    n = 16384
+    s = synth.s_pol(n)
+    p = dict(synth.FLAGS_POL_PRODUCTION)
+    res = []
+    for persistent in (1, 0):
+        e = engine.Engine(n)
+        e.load_system(s, p)
+        e.set_option("persistent_gs", persistent)
+        r = e.energy()
+        r.update(e.dipoles())
+        if persistent:
+            new = s["pos"][500:505] + np.array([0.2, -0.1, 0.15])
+            e.update_atoms(500, new)
+            moved = e.energy()
+            assert moved["polarization_energy"] != r["polarization_energy"]
+            e.update_atoms(500, s["pos"][500:505])
+            assert e.energy()["energy"] == r["energy"]
+        res.append(r)
+        e.close()
+    assert np.abs(res[0]["mu"] - res[1]["mu"]).max() <= 1e-12 * np.abs(res[1]["mu"]).max()
+    assert rel(res[0]["polarization_energy"], res[1]["polarization_energy"]) < 1e-12
+    assert res[0]["polar_iterations"] == res[1]["polar_iterations"] == 4
+
+
 def test_degenerate_sweep_views():
     """Edges of the sweep view: polarization switched on with no polarizable site at all (an empty view), a single
     atom, and views that end exactly on / just past a 64-site block boundary -- Jacobi, ranked Gauss-Seidel and the
