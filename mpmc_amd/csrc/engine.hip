@@ -260,7 +260,8 @@ struct mpmc_hip_ctx {
     // that walk was sorted from (d_rank_used) and energy_end() repeats the call the slow way if they differ
     double *d_rank_used = nullptr;
     unsigned int *d_rankcnt = nullptr;    // neighbour counters of the ranking metric
-    std::vector<int> perm_sorted;         // the walk d_rank_used gives (all atoms, as ranked_array)
+    std::vector<double> rank_saved;       // host copy of the metric d_rank_used holds (download_ranking sorts it on demand)
+    bool perm_ranked = false;             // the last call's sweeps used the ranked walk
     bool rank_used_valid = false;
     // Gauss-Seidel + grand-canonical edits: the sweep ORDER is part of the result, and after insert / remove the
     // engine's slot order is no longer the caller's atom order.  The caller then states the order of the polarizable
@@ -272,9 +273,11 @@ struct mpmc_hip_ctx {
     int opt_spec_rank = 1;
     unsigned long long spec_redos = 0;
     hipEvent_t ev_rank = nullptr;
+    int *h_order = nullptr;               // pinned staging of set_sweep_order (2 x max_npad ints)
+    hipEvent_t ev_order = nullptr;
     double *h_rank = nullptr;             // pinned, max_npad
     int *h_perm = nullptr;                // pinned, max_npad
-    std::vector<int> perm;                // final sweep order (all atoms, as ranked_array)
+    int *h_slotmap = nullptr;             // pinned, max_npad: an atom -> slot map on its way to the device
     // host state
     mpmc_hip_params par;
     bool have_params = false, have_box = false, have_atoms = false;
@@ -531,6 +534,7 @@ extern "C" int mpmc_hip_create(mpmc_hip_ctx **out, int device, int max_atoms) {
     HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_rank, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_order, hipEventDisableTiming));
 #define DALLOC(ptr, count, type) HIPCHK(hipMalloc((void **)&(ptr), (count) * sizeof(type)))
     DALLOC(c->d_x, np, double);
     DALLOC(c->d_y, np, double);
@@ -592,6 +596,7 @@ extern "C" int mpmc_hip_create(mpmc_hip_ctx **out, int device, int max_atoms) {
     HIPCHK(hipHostMalloc((void **)&c->h_gserr, 2 * sizeof(unsigned), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&c->h_rank, np * sizeof(double), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&c->h_perm, np * sizeof(int), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&c->h_slotmap, np * sizeof(int), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&c->h_dirty, kMaxDirty * sizeof(int), hipHostMallocDefault));
     c->stage_cap = 3 * 4096;
     HIPCHK(hipHostMalloc((void **)&c->h_stage, c->stage_cap * sizeof(double), hipHostMallocDefault));
@@ -636,11 +641,14 @@ extern "C" void mpmc_hip_destroy(mpmc_hip_ctx *c) {
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
     if (c->ev_rank) hipEventDestroy(c->ev_rank);
+    if (c->ev_order) hipEventDestroy(c->ev_order);
+    if (c->h_order) hipHostFree(c->h_order);
     if (c->h_res) hipHostFree(c->h_res);
     if (c->h_err) hipHostFree(c->h_err);
     if (c->h_gserr) hipHostFree(c->h_gserr);
     if (c->h_rank) hipHostFree(c->h_rank);
     if (c->h_perm) hipHostFree(c->h_perm);
+    if (c->h_slotmap) hipHostFree(c->h_slotmap);
     if (c->h_dirty) hipHostFree(c->h_dirty);
     if (c->h_stage) hipHostFree(c->h_stage);
     for (auto &e : c->ev_pool) hipEventDestroy(e);
@@ -794,8 +802,8 @@ extern "C" int mpmc_hip_upload(mpmc_hip_ctx *c, int n, const double *x, const do
     c->have_atoms = true;
     c->have_polar_result = false;
     c->lrc_valid = false;
-    c->perm.assign(n, 0);
-    std::iota(c->perm.begin(), c->perm.end(), 0);
+    c->rank_saved.clear();
+    c->perm_ranked = false;
     c->pending.n = 0;
     // view 0: polarizable atoms in atom order
     SweepView &v0 = c->view[0];
@@ -1043,8 +1051,6 @@ extern "C" int mpmc_hip_insert_molecule(mpmc_hip_ctx *c, int count, const double
         c->n += count;
         c->slot_valid.resize(c->n, 0);
         v0.slot_of_atom.resize(c->n, -1);
-        c->perm.resize(c->n);
-        std::iota(c->perm.begin(), c->perm.end(), 0);
         const int npad = round_up(c->n, 128);
         if (npad != c->npad) {  // the tile grids of the pair / field / LRC partials change shape
             c->npad = npad;
@@ -1126,13 +1132,23 @@ extern "C" int mpmc_hip_set_sweep_order(mpmc_hip_ctx *c, int count, const int *s
     v0.nv = count;
     v0.nvpad = std::max(128, round_up(count, 128));
     v0.slot_of_atom.assign(c->n, -1);
-    std::vector<int> hs(c->max_npad, -1);
+    // staged in pinned memory of their own (the ranked view's staging buffers may still be in flight), copied in
+    // stream order: nothing here waits for the device
+    if (!c->h_order) {
+        HIPCHK(hipHostMalloc((void **)&c->h_order, 2 * (size_t)c->max_npad * sizeof(int), hipHostMallocDefault));
+    } else {
+        HIPCHK(hipEventSynchronize(c->ev_order));  // the previous use of the staging buffer has been copied
+    }
+    int *h_idx = c->h_order, *h_slot = c->h_order + c->max_npad;
+    for (int k = 0; k < c->max_npad; ++k) h_slot[k] = -1;
     for (int k = 0; k < count; ++k) {
         v0.slot_of_atom[slots[k]] = k;
-        hs[slots[k]] = k;
+        h_slot[slots[k]] = k;
+        h_idx[k] = slots[k];
     }
-    HIPCHK(hipMemcpy(v0.d_slot, hs.data(), hs.size() * sizeof(int), hipMemcpyHostToDevice));
-    if (count > 0) HIPCHK(hipMemcpy(v0.d_idx, slots, count * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpyAsync(v0.d_slot, h_slot, (size_t)c->max_npad * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    if (count > 0) HIPCHK(hipMemcpyAsync(v0.d_idx, h_idx, count * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipEventRecord(c->ev_order, c->stream));
     v0.pos_valid = false;
     if (keep_prefix) {
         v0.rebuild_from = p0 / 64;  // (C stays "valid": setup_view rebuilds the tail and updates moved atoms' entries)
@@ -1871,7 +1887,17 @@ extern "C" int mpmc_hip_download_ranking(mpmc_hip_ctx *c, double *rank_metric, i
     if (!c || !c->have_atoms) return fail("MPMC_HIP: download_ranking: no configuration");
     HIPCHK(hipSetDevice(c->device));
     if (rank_metric) HIPCHK(hipMemcpy(rank_metric, c->d_rank, c->n * sizeof(double), hipMemcpyDeviceToHost));
-    if (ranked_array) memcpy(ranked_array, c->perm.data(), c->n * sizeof(int));
+    if (ranked_array) {
+        // the reference's ranked_array after update_ranking() (thole_iterative.c:143-164): a stable descending sort of
+        // the identity by the metric -- made here, on demand, from the metric the last ranked call was sorted from
+        std::vector<int> perm(c->n);
+        std::iota(perm.begin(), perm.end(), 0);
+        if (c->perm_ranked && (int)c->rank_saved.size() == c->n) {
+            const double *rk = c->rank_saved.data();
+            std::stable_sort(perm.begin(), perm.end(), [rk](int x, int y) { return rk[x] > rk[y]; });
+        }
+        memcpy(ranked_array, perm.data(), c->n * sizeof(int));
+    }
     return 0;
 }
 
