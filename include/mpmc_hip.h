@@ -102,6 +102,10 @@ typedef struct mpmc_hip_timings {
     int event_pair_count; /* between): what an event pair adds to the kernel it brackets               */
     int spec_rank_redos;  /* polar_gs_ranked: calls repeated because the ranked walk assumed at enqueue time was
                            * not the one the new ranking metric gives (cumulative)              */
+    int resident_calls;   /* energy() calls whose dipole solve ran as one resident launch (option "resident_jacobi";
+                           * cumulative)                                                                       */
+    int resident_fallbacks; /* such calls that were repeated on the multi-launch path because a hand-off of the
+                           * resident kernel timed out (the device was shared); the context then stays there    */
 } mpmc_hip_timings;
 
 const char *mpmc_hip_last_error(void);

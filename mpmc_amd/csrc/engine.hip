@@ -27,6 +27,7 @@
 #include <utility>
 #include <ctime>
 #include <numeric>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -35,6 +36,7 @@
 #include "kernels_polar.h"
 #include "kernels_gs.h"
 #include "kernels_gs_chain.h"
+#include "kernels_resident.h"
 #include "kernels_symv.h"
 #include "kernels_coef.h"
 
@@ -44,6 +46,8 @@ using namespace mpmc;
 // error plumbing
 // ------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
+// contexts alive per device in this process: the resident solver needs the device to itself (kernels_resident.h)
+static std::atomic<int> g_ctx_on_device[64];
 
 static int fail(const char *fmt, ...) {
     char buf[1024];
@@ -133,6 +137,11 @@ struct SweepView {
                                       // blocks in front of it keep their data, the rest is rebuilt at the next energy()
     double *Srow = nullptr, *Zcol = nullptr;  // partial sums of the symmetric sweep
     size_t symcap = 0;
+    // resident Jacobi solver (kernels_resident.h): partial-sum slots (sentinel between calls), published dipoles
+    double *resP = nullptr;
+    int res_pld = 0;
+    bool resP_armed = false;
+    double *respub = nullptr;
     std::vector<int> h_idx;
 };
 
@@ -184,6 +193,19 @@ struct mpmc_hip_ctx {
     bool all_dirty = true;
     int opt_incremental = 1, opt_overlap = 1, opt_symmetric = 1, opt_persistent_gs = 1;
     int opt_gs_fault_sweep = 0;
+    int opt_sweep_alternate = 1;           // "sweep_alternate": pair_sweep_kernel walks each XCD's tiles forwards / backwards in turn
+    int opt_sweep_ring = 0;                // "sweep_ring": coefficient registers per lane of pair_sweep_kernel (0 = all 16 steps)
+    int opt_sweep_ablate = 0;              // timing-only ablations of pair_sweep_kernel (wrong results)
+    int opt_sweep_nt = 0;                  // "sweep_nt": non-temporal coefficient loads in pair_sweep_kernel (0: default policy)
+    int opt_resident = 0;                  // "resident_jacobi": fixed-count Jacobi-type solves as one launch, tiles in registers
+    int opt_res_fault = 0;                 // test hook: the next resident launch loses a hand-off
+    int opt_res_stamps = 0;                // diagnostic: the next resident launches print their hand-off time line
+    int opt_res_side = 0;                  // "resident_side": 1 = feed the LJ/Ewald stream BEFORE the resident launch
+    bool resident_off = false;             // a resident launch gave up once: this context stays on the multi-launch path
+    bool call_resident = false;            // the call in flight used the resident kernel
+    bool force_multi_launch = false;       // while energy_end() repeats such a call
+    bool res_attr_set = false;
+    unsigned long long resident_calls = 0, resident_fallbacks = 0;
     int opt_gs_ablate = 0;                 // timing-only ablations of the chain kernel (wrong results; tools/gs_ablate.py)
     int opt_gs_stamps = 0;                 // diagnostic: time stamps inside the chain kernel (printed by the sweep)
     unsigned long long *d_stamps = nullptr;
@@ -471,6 +493,23 @@ extern "C" int mpmc_hip_set_option(mpmc_hip_ctx *c, const char *name, int value)
         c->opt_gs_stamps = value;  // diagnostic: the next Gauss-Seidel sweeps print where a block's time goes (slow)
     else if (!strcmp(name, "gs_fault_sweep"))
         c->opt_gs_fault_sweep = value;  // test hook: in Gauss-Seidel sweep number `value` (1-based) block 1 never publishes
+    else if (!strcmp(name, "sweep_alternate"))
+        c->opt_sweep_alternate = value;
+    else if (!strcmp(name, "sweep_ring"))
+        c->opt_sweep_ring = value;
+    else if (!strcmp(name, "sweep_ablate"))
+        c->opt_sweep_ablate = value;
+    else if (!strcmp(name, "sweep_nt"))
+        c->opt_sweep_nt = value;
+    else if (!strcmp(name, "resident_jacobi")) {
+        c->opt_resident = value;  // 0: one sweep + one finish launch per iteration (A/B; bit-identical results)
+        if (value) c->resident_off = false;
+    } else if (!strcmp(name, "resident_fault"))
+        c->opt_res_fault = value;  // test hook: the next resident launch loses a hand-off (-> fallback)
+    else if (!strcmp(name, "resident_stamps"))
+        c->opt_res_stamps = value;
+    else if (!strcmp(name, "resident_side"))
+        c->opt_res_side = value;   // 1: the LJ/Ewald stream is fed before the resident launch instead of after it
     else if (!strcmp(name, "pair_coefficients")) {
         c->opt_pair_coef = value;
         c->all_dirty = true;
@@ -606,6 +645,7 @@ extern "C" int mpmc_hip_create(mpmc_hip_ctx **out, int device, int max_atoms) {
     HIPCHK(hipEventCreate(&c->ev_last));
     HIPCHK(hipMemsetAsync(c->d_res, 0, R_COUNT * sizeof(double), c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (device < 64) ++g_ctx_on_device[device];
     *out = c;
     return 0;
 }
@@ -622,6 +662,7 @@ extern "C" void mpmc_hip_destroy(mpmc_hip_ctx *c) {
         fprintf(stderr, "MPMC_HIP graph steps: node updates %.1f us, launch %.1f us per step\n",
                 1e6 * c->graph_update_s / c->graph_launches, 1e6 * c->graph_launch_s / c->graph_launches);
     hipSetDevice(c->device);
+    if (c->device < 64) --g_ctx_on_device[c->device];
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->stream2) hipStreamSynchronize(c->stream2);
     void *dptrs[] = {c->d_x,   c->d_y,     c->d_z,     c->d_q,    c->d_alpha, c->d_eps,      c->d_sig,
@@ -631,7 +672,7 @@ extern "C" void mpmc_hip_destroy(mpmc_hip_ctx *c) {
     for (void *p : dptrs)
         if (p) hipFree(p);
     for (SweepView &v : c->view) {
-        void *vp[] = {v.Srow, v.Minv, v.Tnb, v.mupub, v.gsflags, v.d_idx, v.d_slot, v.px, v.py, v.pz, v.palpha, v.pflags, v.A,    v.C, v.energy_part, v.es,
+        void *vp[] = {v.resP, v.respub, v.Srow, v.Minv, v.Tnb, v.mupub, v.gsflags, v.d_idx, v.d_slot, v.px, v.py, v.pz, v.palpha, v.pflags, v.A,    v.C, v.energy_part, v.es,
                       v.mu0,   v.mu1, v.munew, v.y, v.efind, v.efchg, v.rrms};
         for (void *p : vp)
             if (p) hipFree(p);
@@ -1325,6 +1366,89 @@ static int ensure_static_field(mpmc_hip_ctx *c) {
     return 0;
 }
 
+// ---- resident Jacobi solver (kernels_resident.h)
+template <int K>
+constexpr int resident_lds_bytes() {
+    return (int)std::max(sizeof(ResidentLds<K>), (size_t)kResFinisherLds);
+}
+constexpr int kResMaxK = 5;
+constexpr int kResidentLdsOnePerCu = 84 * 1024;  // more than half a CU's LDS: at most one workgroup per CU
+constexpr int kResidentLdsMax = std::max(kResidentLdsOnePerCu, resident_lds_bytes<kResMaxK>());
+static_assert(kResidentLdsMax <= 160 * 1024, "LDS of a CU");
+typedef void (*ResidentKernel)(ResidentSolve);
+static ResidentKernel resident_kernel_of(int ortho, int K) {
+    switch (K) {
+    case 1: return ortho ? jacobi_resident_kernel<1, 1> : jacobi_resident_kernel<0, 1>;
+    case 2: return ortho ? jacobi_resident_kernel<1, 2> : jacobi_resident_kernel<0, 2>;
+    case 3: return ortho ? jacobi_resident_kernel<1, 3> : jacobi_resident_kernel<0, 3>;
+    case 4: return ortho ? jacobi_resident_kernel<1, 4> : jacobi_resident_kernel<0, 4>;
+    default: return ortho ? jacobi_resident_kernel<1, 5> : jacobi_resident_kernel<0, 5>;
+    }
+}
+static std::vector<const void *> resident_kernels() {
+    std::vector<const void *> v;
+    for (int o = 0; o < 2; ++o)
+        for (int K = 1; K <= kResMaxK; ++K) v.push_back(reinterpret_cast<const void *>(resident_kernel_of(o, K)));
+    return v;
+}
+
+// How a solve of nt blocks is spread over the chip: K tiles per tile workgroup, ngroups of them (+ nt finishers), one
+// or two workgroups per CU -- whichever leaves the fewest tiles per CU (each tile is one wave's work per SIMD and
+// sweep).  ok = false: does not fit (or is not a fixed-count Jacobi-type solve): the multi-launch path runs.
+struct ResidentPlan {
+    bool ok = false;
+    int K = 0, ngroups = 0, lds = 0, nt = 0, ntiles = 0;
+};
+static ResidentPlan resident_plan(const mpmc_hip_ctx *c, const SweepView &v) {
+    ResidentPlan r;
+    const mpmc_hip_params &P = c->par;
+    if (!c->opt_resident || c->resident_off || c->force_multi_launch || !c->opt_pair_coef || !v.C_valid) return r;
+    if (P.polar_zodid || P.polar_gs || P.polar_gs_ranked || P.polar_precision != 0.0) return r;
+    if (P.polar_max_iter < 1 || P.polar_max_iter > kResMaxSweeps) return r;
+    if (c->device < 64 && g_ctx_on_device[c->device].load() > 1) return r;  // co-residency needs the device to itself
+    const int nt = std::max(1, (v.nv + kCoefTile - 1) / kCoefTile);
+    if (nt > kResMaxBlocks) return r;
+    const int ntiles = nt * (nt + 1) / 2, cus = c->num_cus;
+    // one workgroup per CU (the kernel runs one wave per SIMD, 512 registers each); the fewest tiles per workgroup
+    // that fit leave the most CUs' worth of time for the LJ / Ewald stream
+    if (cus - nt <= 0) return r;
+    const int bestK = (ntiles + (cus - nt) - 1) / (cus - nt);
+    if (bestK > kResMaxK) return r;
+    r.ok = true;
+    r.K = bestK;
+    r.nt = nt;
+    r.ntiles = ntiles;
+    r.ngroups = (ntiles + bestK - 1) / bestK;
+    int need = resident_lds_bytes<1>();
+    if (bestK == 2) need = resident_lds_bytes<2>();
+    if (bestK == 3) need = resident_lds_bytes<3>();
+    if (bestK == 4) need = resident_lds_bytes<4>();
+    if (bestK == 5) need = resident_lds_bytes<5>();
+    const bool one = true;
+    r.lds = one ? std::max(need, kResidentLdsOnePerCu) : need;
+    return r;
+}
+
+static int ensure_view_resident(mpmc_hip_ctx *c, SweepView &v) {
+    const int pld = std::min(std::max(1, v.ntld), kResMaxBlocks);
+    const size_t pstride = (size_t)pld * pld * 384;
+    if (!v.resP || v.res_pld != pld) {
+        if (v.resP) hipFree(v.resP);
+        v.resP = nullptr;
+        HIPCHK(hipMalloc((void **)&v.resP, 2 * pstride * sizeof(double)));
+        v.res_pld = pld;
+        v.resP_armed = false;
+    }
+    if (!v.resP_armed) {
+        // both 32-bit halves of the sentinel are the same word
+        static_assert((kGsSentinel >> 32) == (kGsSentinel & 0xffffffffull), "sentinel halves");
+        HIPCHK(hipMemsetD32Async((hipDeviceptr_t)v.resP, (int)(kGsSentinel & 0xffffffffull), 2 * pstride * 2, c->stream));
+        v.resP_armed = true;
+    }
+    if (!v.respub) HIPCHK(hipMalloc((void **)&v.respub, (size_t)kResMaxSweeps * 3 * v.cap * sizeof(double)));
+    return 0;
+}
+
 #include "engine_polar.inc"
 
 // the 16-double result record goes straight into mapped pinned host memory (no copy engine / copy kernel)
@@ -1437,6 +1561,7 @@ static void collect_dirty_blocks(mpmc_hip_ctx *c) {
 // One evaluation, launch by launch (also what stream capture records for the step graph).
 static int enqueue_direct(mpmc_hip_ctx *c) {
     c->recip_chunks = 0;
+    c->call_resident = false;
     if (flush_moves(c)) return -1;
     if (is_timed_call(c)) hipEventRecord(c->ev_first, c->stream);
 
@@ -1794,6 +1919,25 @@ extern "C" int mpmc_hip_energy_end(mpmc_hip_ctx *c, mpmc_hip_result *out) {
         if (rc) return -1;
         if (wait_record()) return -1;
     }
+    if (c->call_resident && c->h_res[R_GS_ERR] != 0.0) {
+        // The resident Jacobi launch gave up on a hand-off (its workgroups were not all running at once: the device
+        // is shared with another process, or a test asked for it).  Nothing it produced is used: the evaluation is
+        // repeated on the multi-launch path, which this context then keeps to; the partial-sum slots are refilled
+        // before the resident kernel could ever run again.
+        ++c->resident_fallbacks;
+        c->resident_off = true;
+        c->view[0].resP_armed = false;
+        c->force_multi_launch = true;
+        ++c->energy_calls;
+        c->ev_next = 0;
+        c->recs.clear();
+        c->gs_used[0] = c->gs_used[1] = false;
+        collect_dirty_blocks(c);
+        const int rc = enqueue_direct(c);
+        c->force_multi_launch = false;
+        if (rc) return -1;
+        if (wait_record()) return -1;
+    }
     clock_gettime(CLOCK_MONOTONIC, &ts2);
     c->host_wait_s += (ts2.tv_sec - ts1.tv_sec) + 1e-9 * (ts2.tv_nsec - ts1.tv_nsec);
     const bool do_polar = c->call_polar, timed_call = c->call_timed;
@@ -1906,6 +2050,8 @@ extern "C" int mpmc_hip_get_timings(mpmc_hip_ctx *c, mpmc_hip_timings *t) {
     memset(t, 0, sizeof(*t));
     t->graph_steps = (int)c->graph_launches;
     t->spec_rank_redos = (int)c->spec_redos;
+    t->resident_calls = (int)c->resident_calls;
+    t->resident_fallbacks = (int)c->resident_fallbacks;
     if (!c->timed) return 0;
     HIPCHK(hipSetDevice(c->device));
     float acc[T_NCLASS] = {0};

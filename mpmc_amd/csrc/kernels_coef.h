@@ -192,9 +192,15 @@ struct CoefFinish {
 // contraction (:119-141), plus the block's share of the energy sums.
 template <int MODE>
 __device__ __forceinline__ void coef_epilogue(const CoefFinish &f, int t, int i, int lane, const double s[3], double al,
-                                              int fl, const double old[3], const double es[3], const double aux[3]) {
+                                              int fl, const double old[3], const double es[3], const double aux[3],
+                                              double m_out[3], double e_out[3]) {
+    // (no implicit FMA contraction: the function is inlined into several kernels -- pair_finish_kernel, the
+    // resident solver's finisher -- whose results are required to agree to the bit)
+#pragma clang fp contract(off)
     const bool valid = fl & kValid;
     double e_i = 0.0, r_i = 0.0, emax_i = 0.0;
+    m_out[0] = m_out[1] = m_out[2] = 0.0;
+    e_out[0] = e_out[1] = e_out[2] = 0.0;
     if ((MODE == kSweepJacobi && (al == 0.0 || !valid)) || (MODE == kSweepPalmo && !valid)) {
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
@@ -209,7 +215,9 @@ __device__ __forceinline__ void coef_epilogue(const CoefFinish &f, int t, int i,
             const double e = -s[p];
             const double nw = al * (es[p] + e);
             f.ef_induced[3 * i + p] = e;
+            e_out[p] = e;
             m[p] = f.sp.w_new * nw + f.sp.w_old * old[p];
+            m_out[p] = m[p];
             f.out[3 * i + p] = m[p];
             const double d = nw - old[p];
             d2 += d * d;
@@ -326,45 +334,27 @@ __global__ __launch_bounds__(64 * kCoefFinishGroups) void pair_finish_kernel(int
         for (int k = 0; k < kCoefFinishGroups; ++k) acc += part[k][p][lane];
         s[p] = acc;
     }
-    coef_epilogue<MODE>(f, t, i, lane, s, al, fl, old, es, aux);
+    double m_new[3], e_new[3];
+    coef_epilogue<MODE>(f, t, i, lane, s, al, fl, old, es, aux, m_new, e_new);
 }
 
-template <int ORTHO>
-__global__ __launch_bounds__(64 * kCoefWaves) void pair_sweep_kernel(const double2 *__restrict__ C, int nt, int ntld,
-                                                                       const double *__restrict__ x,
-                                                                       const double *__restrict__ y,
-                                                                       const double *__restrict__ z,
-                                                                       const double *__restrict__ mu, DevBox bx,
-                                                                       double *__restrict__ Srow,
-                                                                       double *__restrict__ Zcol) {
-    int ti, tj;
-    upper_tile_of(blockIdx.x, nt, ti, tj);
-    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const bool diag = (ti == tj);
-    __shared__ double2 jxy[64], jzm[64], jmm[64];  // {x, y}, {z, mu_x}, {mu_y, mu_z} of the column atoms
-    __shared__ double red[kCoefWaves][6][64];
-    if (w == 0) {
-        const int j = 64 * tj + l;
-        jxy[l] = make_double2(x[j], y[j]);
-        jzm[l] = make_double2(z[j], mu[3 * j]);
-        jmm[l] = make_double2(mu[3 * j + 1], mu[3 * j + 2]);
-    }
-    const int i = 64 * ti + l;
-    const double xi = x[i], yi = y[i], zi = z[i];
-    const double mix = mu[3 * i], miy = mu[3 * i + 1], miz = mu[3 * i + 2];
-    const double2 *tile = C + coef_tile_index(ti, tj, ntld) * (kCoefTile * kCoefTile) + (size_t)(kCoefSteps * w) * 64 + l;
-    double2 c[kCoefSteps];
-#pragma unroll
-    for (int k = 0; k < kCoefSteps; ++k) c[k] = stream_load_coef(tile + 64 * k);
-    __syncthreads();
-    double sx = 0.0, sy = 0.0, sz = 0.0, zx = 0.0, zy = 0.0, zz = 0.0;
+// One wave's quarter (steps 16 w .. 16 w + 15) of a tile's product: row sums stay in the lane, the column sums follow
+// their column atom one lane per step.  Shared by pair_sweep_kernel and the resident solver (kernels_resident.h), which
+// must agree to the bit: every product / sum is an explicit fma or a lone multiplication.
+// (PREMUL: c[k].y already holds -3 c5 -- the resident solver multiplies once when it loads a tile; same product, same bits)
+template <int ORTHO, int TIGHT = 0, int PREMUL = 0>
+__device__ __forceinline__ void tile_quarter_product(const double2 (&c)[kCoefSteps], int l, int w, double xi, double yi,
+                                                     double zi, double mix, double miy, double miz, const double2 *jxy,
+                                                     const double2 *jzm, const double2 *jmm, const DevBox &bx, double &sx,
+                                                     double &sy, double &sz, double &zx, double &zy, double &zz) {
+    sx = sy = sz = zx = zy = zz = 0.0;
 #pragma unroll
     for (int k = 0; k < kCoefSteps; ++k) {
         const int jj = (l + kCoefSteps * w + k) & 63;
         const double2 pa = jxy[jj], pb = jzm[jj], pm = jmm[jj];
         double dx, dy, dz;
         image_displacement<ORTHO>(bx, xi - pa.x, yi - pa.y, zi - pb.x, dx, dy, dz);
-        const double c3 = c[k].x, c5m = -3.0 * c[k].y;
+        const double c3 = c[k].x, c5m = PREMUL ? c[k].y : -3.0 * c[k].y;
         // row: T mu_j = c3 mu_j - 3 c5 (d . mu_j) d
         const double wj = c5m * fma(dz, pm.y, fma(dy, pm.x, dx * pb.y));
         sx = fma(wj, dx, fma(c3, pb.y, sx));
@@ -380,6 +370,102 @@ __global__ __launch_bounds__(64 * kCoefWaves) void pair_sweep_kernel(const doubl
         zx = fma(wi, dx, fma(c3, mix, zx));
         zy = fma(wi, dy, fma(c3, miy, zy));
         zz = fma(wi, dz, fma(c3, miz, zz));
+        // TIGHT: the scheduler may not move work across steps (the resident solver holds three tiles in registers and has
+        // ~60 VGPRs for everything else; hoisting the LDS reads of later steps costs more registers than it has)
+        if (TIGHT) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+
+// The same quarter product with the coefficients streamed through a ring of RING registers instead of all 16 being
+// requested up front: 32 instead of 64 VGPRs of coefficients per lane, so that six workgroups (instead of four) fit a
+// CU and the 1 326 tiles of a 3 300-site view are in flight in ONE round.  Same operations in the same order.
+template <int ORTHO, int NT, int RING>
+__device__ __forceinline__ void tile_quarter_product_ring(const double2 *tile, int l, int w, double xi, double yi, double zi,
+                                                          double mix, double miy, double miz, const double2 *jxy,
+                                                          const double2 *jzm, const double2 *jmm, const DevBox &bx,
+                                                          double2 (&c)[RING], double &sx, double &sy, double &sz,
+                                                          double &zx, double &zy, double &zz) {
+    sx = sy = sz = zx = zy = zz = 0.0;
+#pragma unroll
+    for (int k = 0; k < kCoefSteps; ++k) {
+        const int jj = (l + kCoefSteps * w + k) & 63;
+        const double2 pa = jxy[jj], pb = jzm[jj], pm = jmm[jj];
+        double dx, dy, dz;
+        image_displacement<ORTHO>(bx, xi - pa.x, yi - pa.y, zi - pb.x, dx, dy, dz);
+        const double c3 = c[k % RING].x, c5m = -3.0 * c[k % RING].y;
+        if (k + RING < kCoefSteps) c[k % RING] = NT ? stream_load_coef(tile + 64 * (k + RING)) : tile[64 * (k + RING)];
+        const double wj = c5m * fma(dz, pm.y, fma(dy, pm.x, dx * pb.y));
+        sx = fma(wj, dx, fma(c3, pb.y, sx));
+        sy = fma(wj, dy, fma(c3, pm.x, sy));
+        sz = fma(wj, dz, fma(c3, pm.y, sz));
+        if (k > 0) {
+            zx = wave_rotate_down(zx);
+            zy = wave_rotate_down(zy);
+            zz = wave_rotate_down(zz);
+        }
+        const double wi = c5m * fma(dz, miz, fma(dy, miy, dx * mix));
+        zx = fma(wi, dx, fma(c3, mix, zx));
+        zy = fma(wi, dy, fma(c3, miy, zy));
+        zz = fma(wi, dz, fma(c3, miz, zz));
+    }
+}
+
+// (NT: non-temporal coefficient loads; 0 = default cache policy, which lets the tiles stay in the 256-MB Infinity Cache
+//  between the sweeps of a solve and between MC steps when the whole set fits)
+// (ABLATE, timing only -- results are wrong: 1 = the tile is loaded but not multiplied, 2 = multiplied but not loaded)
+template <int ORTHO, int NT = 1, int ABLATE = 0, int RING = 0>
+__global__ __launch_bounds__(64 * kCoefWaves) void pair_sweep_kernel(const double2 *__restrict__ C, int nt, int ntld,
+                                                                       const double *__restrict__ x,
+                                                                       const double *__restrict__ y,
+                                                                       const double *__restrict__ z,
+                                                                       const double *__restrict__ mu, DevBox bx,
+                                                                       double *__restrict__ Srow,
+                                                                       double *__restrict__ Zcol, int rev) {
+    // Workgroups are placed on the 8 XCDs round-robin by their index, so XCD x always multiplies the tiles x, x + 8, ...
+    // With `rev` alternating from sweep to sweep it walks them forwards, then backwards: the tiles it read LAST in one
+    // sweep (still in its 4-MB L2) are the ones it reads FIRST in the next.
+    int ti, tj;
+    {
+        const int ntiles = nt * (nt + 1) / 2;
+        const int b = blockIdx.x, x = b & 7, i = b >> 3;
+        const int n_x = (ntiles - x + 7) >> 3;
+        upper_tile_of(x + 8 * (rev ? n_x - 1 - i : i), nt, ti, tj);
+    }
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const bool diag = (ti == tj);
+    __shared__ double2 jxy[64], jzm[64], jmm[64];  // {x, y}, {z, mu_x}, {mu_y, mu_z} of the column atoms
+    __shared__ double red[kCoefWaves][6][64];
+    if (w == 0) {
+        const int j = 64 * tj + l;
+        jxy[l] = make_double2(x[j], y[j]);
+        jzm[l] = make_double2(z[j], mu[3 * j]);
+        jmm[l] = make_double2(mu[3 * j + 1], mu[3 * j + 2]);
+    }
+    const int i = 64 * ti + l;
+    const double xi = x[i], yi = y[i], zi = z[i];
+    const double mix = mu[3 * i], miy = mu[3 * i + 1], miz = mu[3 * i + 2];
+    const double2 *tile = C + coef_tile_index(ti, tj, ntld) * (kCoefTile * kCoefTile) + (size_t)(kCoefSteps * w) * 64 + l;
+    double2 c[RING > 0 ? RING : kCoefSteps];
+#pragma unroll
+    for (int k = 0; k < (RING > 0 ? RING : kCoefSteps); ++k) {
+        if (ABLATE == 2) c[k] = make_double2(xi + k, yi - k);
+        else c[k] = NT ? stream_load_coef(tile + 64 * k) : tile[64 * k];
+    }
+    __syncthreads();
+    double sx, sy, sz, zx, zy, zz;
+    if constexpr (RING > 0) {
+        tile_quarter_product_ring<ORTHO, NT, RING>(tile, l, w, xi, yi, zi, mix, miy, miz, jxy, jzm, jmm, bx, c, sx, sy, sz, zx,
+                                                   zy, zz);
+    } else if constexpr (ABLATE == 1) {
+        sx = sy = sz = zx = zy = zz = 0.0;
+#pragma unroll
+        for (int k = 0; k < kCoefSteps; ++k) {
+            sx += c[k].x;
+            zx += c[k].y;
+        }
+    } else {
+        tile_quarter_product<ORTHO>(c, l, w, xi, yi, zi, mix, miy, miz, jxy, jzm, jmm, bx, sx, sy, sz, zx, zy, zz);
     }
     red[w][0][l] = sx;
     red[w][1][l] = sy;

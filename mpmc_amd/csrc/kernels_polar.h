@@ -666,7 +666,9 @@ __global__ __launch_bounds__(64 * kFieldGroups) void init_view_kernel(int nv, in
                                                                        double *__restrict__ rrms,
                                                                        unsigned long long *__restrict__ errmax,
                                                                        unsigned *__restrict__ gsflags0,
-                                                                       unsigned *__restrict__ gsflags1) {
+                                                                       unsigned *__restrict__ gsflags1,
+                                                                       double *__restrict__ pub, int pub_slabs,
+                                                                       size_t pub_stride) {
     __shared__ double red[kFieldGroups][3][kWave];
     const int k = blockIdx.x * kWave + (threadIdx.x & 63);
     if (blockIdx.x == 0 && threadIdx.x < 256) errmax[threadIdx.x] = 0ull;
@@ -684,9 +686,17 @@ __global__ __launch_bounds__(64 * kFieldGroups) void init_view_kernel(int nv, in
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
         es[3 * k + p] = e[p];
-        mu[3 * k + p] = al * e[p] * scale;
+        const double m0 = al * e[p] * scale;
+        mu[3 * k + p] = m0;
         ef_induced[3 * k + p] = 0.0;
         ef_change[3 * k + p] = 0.0;
+        // resident solver (kernels_resident.h): the initial dipoles, planar per block, in slab 0 of its hand-off
+        // buffer; the slabs of the later sweeps are armed with the sentinel
+        if (pub) {
+            const size_t o = 192 * (size_t)blockIdx.x + 64 * p + (threadIdx.x & 63);
+            pub[o] = m0;
+            for (int sl = 1; sl < pub_slabs; ++sl) pub[sl * pub_stride + o] = __longlong_as_double(0x7ff8dead7ff8deadll);
+        }
     }
     rrms[k] = 0.0;
 }

@@ -93,6 +93,8 @@ class Timings(C.Structure):
         ("event_pair_ms", C.c_float),
         ("event_pair_count", C.c_int),
         ("spec_rank_redos", C.c_int),
+        ("resident_calls", C.c_int),
+        ("resident_fallbacks", C.c_int),
     ]
 
 
