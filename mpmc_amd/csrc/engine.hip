@@ -194,9 +194,9 @@ struct mpmc_hip_ctx {
     int opt_incremental = 1, opt_overlap = 1, opt_symmetric = 1, opt_persistent_gs = 1;
     int opt_gs_fault_sweep = 0;
     int opt_sweep_alternate = 1;           // "sweep_alternate": pair_sweep_kernel walks each XCD's tiles forwards / backwards in turn
-    int opt_sweep_ring = 0;                // "sweep_ring": coefficient registers per lane of pair_sweep_kernel (0 = all 16 steps)
     int opt_sweep_ablate = 0;              // timing-only ablations of pair_sweep_kernel (wrong results)
-    int opt_sweep_nt = 0;                  // "sweep_nt": non-temporal coefficient loads in pair_sweep_kernel (0: default policy)
+    int opt_sweep_nt = -1;                 // "sweep_nt": non-temporal coefficient loads in pair_sweep_kernel: 1 always, 0 never,
+                                           // -1 = only when the tile set cannot stay in the 256-MB Infinity Cache
     int opt_resident = 0;                  // "resident_jacobi": fixed-count Jacobi-type solves as one launch, tiles in registers
     int opt_res_fault = 0;                 // test hook: the next resident launch loses a hand-off
     int opt_res_stamps = 0;                // diagnostic: the next resident launches print their hand-off time line
@@ -495,8 +495,6 @@ extern "C" int mpmc_hip_set_option(mpmc_hip_ctx *c, const char *name, int value)
         c->opt_gs_fault_sweep = value;  // test hook: in Gauss-Seidel sweep number `value` (1-based) block 1 never publishes
     else if (!strcmp(name, "sweep_alternate"))
         c->opt_sweep_alternate = value;
-    else if (!strcmp(name, "sweep_ring"))
-        c->opt_sweep_ring = value;
     else if (!strcmp(name, "sweep_ablate"))
         c->opt_sweep_ablate = value;
     else if (!strcmp(name, "sweep_nt"))

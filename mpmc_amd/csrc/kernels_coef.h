@@ -377,44 +377,10 @@ __device__ __forceinline__ void tile_quarter_product(const double2 (&c)[kCoefSte
 }
 
 
-// The same quarter product with the coefficients streamed through a ring of RING registers instead of all 16 being
-// requested up front: 32 instead of 64 VGPRs of coefficients per lane, so that six workgroups (instead of four) fit a
-// CU and the 1 326 tiles of a 3 300-site view are in flight in ONE round.  Same operations in the same order.
-template <int ORTHO, int NT, int RING>
-__device__ __forceinline__ void tile_quarter_product_ring(const double2 *tile, int l, int w, double xi, double yi, double zi,
-                                                          double mix, double miy, double miz, const double2 *jxy,
-                                                          const double2 *jzm, const double2 *jmm, const DevBox &bx,
-                                                          double2 (&c)[RING], double &sx, double &sy, double &sz,
-                                                          double &zx, double &zy, double &zz) {
-    sx = sy = sz = zx = zy = zz = 0.0;
-#pragma unroll
-    for (int k = 0; k < kCoefSteps; ++k) {
-        const int jj = (l + kCoefSteps * w + k) & 63;
-        const double2 pa = jxy[jj], pb = jzm[jj], pm = jmm[jj];
-        double dx, dy, dz;
-        image_displacement<ORTHO>(bx, xi - pa.x, yi - pa.y, zi - pb.x, dx, dy, dz);
-        const double c3 = c[k % RING].x, c5m = -3.0 * c[k % RING].y;
-        if (k + RING < kCoefSteps) c[k % RING] = NT ? stream_load_coef(tile + 64 * (k + RING)) : tile[64 * (k + RING)];
-        const double wj = c5m * fma(dz, pm.y, fma(dy, pm.x, dx * pb.y));
-        sx = fma(wj, dx, fma(c3, pb.y, sx));
-        sy = fma(wj, dy, fma(c3, pm.x, sy));
-        sz = fma(wj, dz, fma(c3, pm.y, sz));
-        if (k > 0) {
-            zx = wave_rotate_down(zx);
-            zy = wave_rotate_down(zy);
-            zz = wave_rotate_down(zz);
-        }
-        const double wi = c5m * fma(dz, miz, fma(dy, miy, dx * mix));
-        zx = fma(wi, dx, fma(c3, mix, zx));
-        zy = fma(wi, dy, fma(c3, miy, zy));
-        zz = fma(wi, dz, fma(c3, miz, zz));
-    }
-}
-
 // (NT: non-temporal coefficient loads; 0 = default cache policy, which lets the tiles stay in the 256-MB Infinity Cache
 //  between the sweeps of a solve and between MC steps when the whole set fits)
 // (ABLATE, timing only -- results are wrong: 1 = the tile is loaded but not multiplied, 2 = multiplied but not loaded)
-template <int ORTHO, int NT = 1, int ABLATE = 0, int RING = 0>
+template <int ORTHO, int NT = 1, int ABLATE = 0>
 __global__ __launch_bounds__(64 * kCoefWaves) void pair_sweep_kernel(const double2 *__restrict__ C, int nt, int ntld,
                                                                        const double *__restrict__ x,
                                                                        const double *__restrict__ y,
@@ -446,18 +412,15 @@ __global__ __launch_bounds__(64 * kCoefWaves) void pair_sweep_kernel(const doubl
     const double xi = x[i], yi = y[i], zi = z[i];
     const double mix = mu[3 * i], miy = mu[3 * i + 1], miz = mu[3 * i + 2];
     const double2 *tile = C + coef_tile_index(ti, tj, ntld) * (kCoefTile * kCoefTile) + (size_t)(kCoefSteps * w) * 64 + l;
-    double2 c[RING > 0 ? RING : kCoefSteps];
+    double2 c[kCoefSteps];
 #pragma unroll
-    for (int k = 0; k < (RING > 0 ? RING : kCoefSteps); ++k) {
+    for (int k = 0; k < kCoefSteps; ++k) {
         if (ABLATE == 2) c[k] = make_double2(xi + k, yi - k);
         else c[k] = NT ? stream_load_coef(tile + 64 * k) : tile[64 * k];
     }
     __syncthreads();
     double sx, sy, sz, zx, zy, zz;
-    if constexpr (RING > 0) {
-        tile_quarter_product_ring<ORTHO, NT, RING>(tile, l, w, xi, yi, zi, mix, miy, miz, jxy, jzm, jmm, bx, c, sx, sy, sz, zx,
-                                                   zy, zz);
-    } else if constexpr (ABLATE == 1) {
+    if constexpr (ABLATE == 1) {
         sx = sy = sz = zx = zy = zz = 0.0;
 #pragma unroll
         for (int k = 0; k < kCoefSteps; ++k) {
@@ -508,9 +471,14 @@ __global__ __launch_bounds__(64 * kCoefWaves) void pair_upper_kernel(const doubl
                                                                        const double *__restrict__ y,
                                                                        const double *__restrict__ z,
                                                                        const double *__restrict__ mu, DevBox bx,
-                                                                       double *__restrict__ Srow) {
+                                                                       double *__restrict__ Srow, int rev) {
     int ti, tj;
-    upper_tile_of(blockIdx.x, nt, ti, tj);
+    {   // XCD-aware order, alternating from sweep to sweep (see pair_sweep_kernel)
+        const int ntiles = nt * (nt + 1) / 2;
+        const int b = blockIdx.x, xc = b & 7, i = b >> 3;
+        const int n_x = (ntiles - xc + 7) >> 3;
+        upper_tile_of(xc + 8 * (rev ? n_x - 1 - i : i), nt, ti, tj);
+    }
     const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
     const bool diag = (ti == tj);
     __shared__ double2 jxy[64], jzm[64], jmm[64];
@@ -526,7 +494,7 @@ __global__ __launch_bounds__(64 * kCoefWaves) void pair_upper_kernel(const doubl
     const double2 *tile = C + coef_tile_index(ti, tj, ntld) * (kCoefTile * kCoefTile) + (size_t)(kCoefSteps * w) * 64 + l;
     double2 c[kCoefSteps];
 #pragma unroll
-    for (int k = 0; k < kCoefSteps; ++k) c[k] = stream_load_coef(tile + 64 * k);
+    for (int k = 0; k < kCoefSteps; ++k) c[k] = tile[64 * k];  // default policy: the set is re-read every sweep
     __syncthreads();
     double sx = 0.0, sy = 0.0, sz = 0.0;
 #pragma unroll

@@ -45,10 +45,10 @@ for rep in range(2):
         sw, cnt = 0.0, 0
         for a, c in firsts[:40]:
             e.update_atoms(a, pos[a:a + c] + r2.normal(scale=0.05, size=3))
-            e.energy()
+            last = e.energy()
             t = e.timings()
             sw += t["sweep_ms"]
             cnt += t["sweep_count"]
-        print("%s %s=%d: %.0f energy()/s (%.1f us), sweep launch %.2f us (n=%d)" %
-              (name, opt, v, 500 / dt, 2000 * dt, 1000 * sw / max(1, cnt), cnt), flush=True)
+        print("%s %s=%d: %.0f energy()/s (%.1f us), sweep launch %.2f us (n=%d)   U_pol %r" %
+              (name, opt, v, 500 / dt, 2000 * dt, 1000 * sw / max(1, cnt), cnt, last["polarization_energy"]), flush=True)
         e.close()
