@@ -357,7 +357,9 @@ def main():
     avg = WalkerAverages(reducer=AbiReducer(chain) if pooled else None)
 
     for var, opt in (("MPMC_OVERLAP", "overlap_streams"), ("MPMC_SIDE_AFTER", "side_after"),
-                     ("MPMC_STEP_GRAPH", "step_graph"), ("MPMC_SYM_MODE", "sym_mode"), ("MPMC_GS_DEBUG", "persistent_gs")):
+                     ("MPMC_STEP_GRAPH", "step_graph"), ("MPMC_SYM_MODE", "sym_mode"), ("MPMC_GS_DEBUG", "persistent_gs"),
+                     ("MPMC_RESIDENT", "resident_jacobi"), ("MPMC_SWEEP_ALTERNATE", "sweep_alternate"),
+                     ("MPMC_SWEEP_NT", "sweep_nt")):
         if os.environ.get(var):
             chain.set_option(opt, int(os.environ[var]))
     if args.full_sweep or args.full_rebuild or args.expanded_matrix:
@@ -461,6 +463,13 @@ def main():
             sweep_bytes = (max(nblk - 1, 0) * max(nblk - 2, 0) / 2) * 4096 * 16 + max(nblk - 1, 0) * 4096 * 48 \
                 + nblk * 18432 * 8 + 6 * m3 * 8
             kernel_name = "gs_chain_kernel"
+        elif not expanded and acc.get("resident_calls", 0) > 0 and acc["sweep_count"] <= nprobe + 1:
+            # small views: the whole solve is ONE launch (jacobi_resident_kernel) whose tiles stay in registers; priced
+            # at the bytes the sweeps of the solve need algorithmically (n_iter passes over the coefficients), so this
+            # is an EFFECTIVE bandwidth -- the launch itself reads the coefficients from memory once
+            n_iter = int(flags.get("polar_max_iter", 10))
+            sweep_bytes = n_iter * (n_pol * (n_pol - 1) / 2 * 16 + 3 * m3 * 8)
+            kernel_name = "jacobi_resident_kernel (%d sweeps in one launch, tiles held in registers: effective bandwidth)" % n_iter
         elif not expanded:
             sweep_bytes = n_pol * (n_pol - 1) / 2 * 16 + 3 * m3 * 8
             kernel_name = "pair_sweep_kernel"

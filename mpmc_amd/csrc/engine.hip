@@ -197,7 +197,7 @@ struct mpmc_hip_ctx {
     int opt_sweep_ablate = 0;              // timing-only ablations of pair_sweep_kernel (wrong results)
     int opt_sweep_nt = -1;                 // "sweep_nt": non-temporal coefficient loads in pair_sweep_kernel: 1 always, 0 never,
                                            // -1 = only when the tile set cannot stay in the 256-MB Infinity Cache
-    int opt_resident = 0;                  // "resident_jacobi": fixed-count Jacobi-type solves as one launch, tiles in registers
+    int opt_resident = 1;                  // "resident_jacobi": fixed-count Jacobi-type solves as one launch, tiles in registers
     int opt_res_fault = 0;                 // test hook: the next resident launch loses a hand-off
     int opt_res_stamps = 0;                // diagnostic: the next resident launches print their hand-off time line
     int opt_res_side = 0;                  // "resident_side": 1 = feed the LJ/Ewald stream BEFORE the resident launch
@@ -1369,19 +1369,14 @@ template <int K>
 constexpr int resident_lds_bytes() {
     return (int)std::max(sizeof(ResidentLds<K>), (size_t)kResFinisherLds);
 }
-constexpr int kResMaxK = 5;
+constexpr int kResMaxK = 1;
 constexpr int kResidentLdsOnePerCu = 84 * 1024;  // more than half a CU's LDS: at most one workgroup per CU
 constexpr int kResidentLdsMax = std::max(kResidentLdsOnePerCu, resident_lds_bytes<kResMaxK>());
 static_assert(kResidentLdsMax <= 160 * 1024, "LDS of a CU");
 typedef void (*ResidentKernel)(ResidentSolve);
 static ResidentKernel resident_kernel_of(int ortho, int K) {
-    switch (K) {
-    case 1: return ortho ? jacobi_resident_kernel<1, 1> : jacobi_resident_kernel<0, 1>;
-    case 2: return ortho ? jacobi_resident_kernel<1, 2> : jacobi_resident_kernel<0, 2>;
-    case 3: return ortho ? jacobi_resident_kernel<1, 3> : jacobi_resident_kernel<0, 3>;
-    case 4: return ortho ? jacobi_resident_kernel<1, 4> : jacobi_resident_kernel<0, 4>;
-    default: return ortho ? jacobi_resident_kernel<1, 5> : jacobi_resident_kernel<0, 5>;
-    }
+    (void)K;  // one tile per tile workgroup is the only geometry in use (see resident_plan)
+    return ortho ? jacobi_resident_kernel<1, 1> : jacobi_resident_kernel<0, 1>;
 }
 static std::vector<const void *> resident_kernels() {
     std::vector<const void *> v;
@@ -1407,21 +1402,19 @@ static ResidentPlan resident_plan(const mpmc_hip_ctx *c, const SweepView &v) {
     const int nt = std::max(1, (v.nv + kCoefTile - 1) / kCoefTile);
     if (nt > kResMaxBlocks) return r;
     const int ntiles = nt * (nt + 1) / 2, cus = c->num_cus;
-    // one workgroup per CU (the kernel runs one wave per SIMD, 512 registers each); the fewest tiles per workgroup
-    // that fit leave the most CUs' worth of time for the LJ / Ewald stream
-    if (cus - nt <= 0) return r;
-    const int bestK = (ntiles + (cus - nt) - 1) / (cus - nt);
-    if (bestK > kResMaxK) return r;
+    // One workgroup per CU, one tile per tile workgroup: views of up to 21 blocks (1 344 polarizable sites).  Larger
+    // views were tried with 2-5 tiles per workgroup (kernel template parameter K) and with two workgroups per CU: the
+    // coefficient set of the 4096-atom boxes fits the register files only with one wave per SIMD or with spills, the
+    // product phase then takes 2 us per tile instead of 1.25, and the LJ / Ewald stream no longer overlaps -- slower than
+    // the multi-launch path there.
+    if (ntiles + nt > cus) return r;
+    const int bestK = 1;
     r.ok = true;
     r.K = bestK;
     r.nt = nt;
     r.ntiles = ntiles;
-    r.ngroups = (ntiles + bestK - 1) / bestK;
-    int need = resident_lds_bytes<1>();
-    if (bestK == 2) need = resident_lds_bytes<2>();
-    if (bestK == 3) need = resident_lds_bytes<3>();
-    if (bestK == 4) need = resident_lds_bytes<4>();
-    if (bestK == 5) need = resident_lds_bytes<5>();
+    r.ngroups = ntiles;
+    const int need = resident_lds_bytes<1>();
     const bool one = true;
     r.lds = one ? std::max(need, kResidentLdsOnePerCu) : need;
     return r;

@@ -193,7 +193,7 @@ struct CoefFinish {
 template <int MODE>
 __device__ __forceinline__ void coef_epilogue(const CoefFinish &f, int t, int i, int lane, const double s[3], double al,
                                               int fl, const double old[3], const double es[3], const double aux[3],
-                                              double m_out[3], double e_out[3]) {
+                                              double m_out[3], double e_out[3], bool want_sums = true) {
     // (no implicit FMA contraction: the function is inlined into several kernels -- pair_finish_kernel, the
     // resident solver's finisher -- whose results are required to agree to the bit)
 #pragma clang fp contract(off)
@@ -245,11 +245,14 @@ __device__ __forceinline__ void coef_epilogue(const CoefFinish &f, int t, int i,
         const double rr = f.rrms[i];
         r_i = isfinite(rr) ? rr : 0.0;
     }
-    e_i = wave_sum(e_i);
-    r_i = wave_sum(r_i);
-    if (lane == 0) {
-        f.energy_part[2 * t] = e_i;
-        f.energy_part[2 * t + 1] = r_i;
+    // (the block's energy / RRMS sums are read after the LAST iteration only; the resident solver skips them before)
+    if (want_sums) {
+        e_i = wave_sum(e_i);
+        r_i = wave_sum(r_i);
+        if (lane == 0) {
+            f.energy_part[2 * t] = e_i;
+            f.energy_part[2 * t + 1] = r_i;
+        }
     }
     // are_we_done_yet (thole_iterative.c:104-113) needs max (new-old)^2, and only when the stopping rule is a
     // precision: one atomic per wave after a lane reduction (one per lane, all on one address, cost 3 us of the

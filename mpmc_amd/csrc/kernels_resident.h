@@ -88,21 +88,21 @@ __device__ __forceinline__ void st_agent_u64(double *p, unsigned long long v) {
 // Returns false on a give-up (sticky error set by this or another thread).
 template <int N>
 __device__ __forceinline__ bool res_poll(const double *(&a)[N], const bool (&on)[N], unsigned long long (&v)[N],
-                                         unsigned *flags) {
-#pragma unroll
-    for (int r = 0; r < N; ++r) v[r] = on[r] ? ld_agent_u64(reinterpret_cast<const unsigned long long *>(a[r])) : 0ull;
+                                         unsigned *flags, unsigned &iters) {
+    // Every pass re-reads ALL wanted values with back-to-back loads (no branch per value: with one, the compiler's wait
+    // placement turned a pass into several dependent round trips).  A slot that has been seen valid stays valid until
+    // its single consumer re-arms it, so a pass in which every value is valid is a consistent set.
     for (unsigned it = 0; it < kResSpinLimit; ++it) {
+#pragma unroll
+        for (int r = 0; r < N; ++r) v[r] = ld_agent_u64(reinterpret_cast<const unsigned long long *>(a[r]));
         bool all = true;
 #pragma unroll
-        for (int r = 0; r < N; ++r) {
-            if (on[r] && v[r] == kGsSentinel) {
-                v[r] = ld_agent_u64(reinterpret_cast<const unsigned long long *>(a[r]));
-                all = false;
-            }
+        for (int r = 0; r < N; ++r) all = all && (!on[r] || v[r] != kGsSentinel);
+        if (all) {
+            iters = it;
+            return true;
         }
-        if (all) return true;
         if ((it & 63u) == 63u && res_failed(flags)) return false;
-        __builtin_amdgcn_s_sleep(1);
     }
     const void *stuck = nullptr;
 #pragma unroll
@@ -115,27 +115,26 @@ __device__ __forceinline__ bool res_poll(const double *(&a)[N], const bool (&on)
 // The finisher's form: NT terms of three components each at base + off[t] + 64 q (32-bit offsets instead of 3 NT pointers).
 template <int NT>
 __device__ __forceinline__ bool res_poll_terms(const double *base, const unsigned (&off)[NT], const bool (&on)[NT],
-                                               unsigned long long (&v)[NT][3], unsigned *flags) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int q = 0; q < 3; ++q)
-            v[t][q] = on[t] ? ld_agent_u64(reinterpret_cast<const unsigned long long *>(base + off[t] + 64 * q)) : 0ull;
+                                               unsigned long long (&v)[NT][3], unsigned *flags, unsigned &iters) {
     for (unsigned it = 0; it < kResSpinLimit; ++it) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (!on[t]) continue;  // wave-uniform
+#pragma unroll
+            for (int q = 0; q < 3; ++q) v[t][q] = ld_agent_u64(reinterpret_cast<const unsigned long long *>(base + off[t] + 64 * q));
+        }
         bool all = true;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
+            if (!on[t]) continue;
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                if (on[t] && v[t][q] == kGsSentinel) {
-                    v[t][q] = ld_agent_u64(reinterpret_cast<const unsigned long long *>(base + off[t] + 64 * q));
-                    all = false;
-                }
-            }
+            for (int q = 0; q < 3; ++q) all = all && (v[t][q] != kGsSentinel);
         }
-        if (all) return true;
+        if (all) {
+            iters = it;
+            return true;
+        }
         if ((it & 63u) == 63u && res_failed(flags)) return false;
-        __builtin_amdgcn_s_sleep(1);
     }
     res_give_up(flags, base);
     return false;
@@ -205,6 +204,88 @@ __global__ __launch_bounds__(kResThreads, 1) void jacobi_resident_kernel(Residen
         f.sp.want_err = 0;
         f.sp.err_slot = 0;
         double s[3] = {0.0, 0.0, 0.0};
+        if (nt <= kCoefFinishGroups) {
+            // ---- up to 16 blocks: every term group holds one term, so ONE wave polls all of them (48 loads per lane in
+            // flight) and adds them in pair_finish_kernel's order in registers: no LDS, no barrier on the sweep's
+            // critical path.  (part[g] = ((0 + x) + 0 + 0 + 0), acc = sum_g part[g]: the zeros are added too, so that
+            // signed zeros come out as they do there.)
+            if (w != 0) return;
+            for (int k = 1; k <= p.niter; ++k) {
+                double *Pk = p.P + (size_t)(k & 1) * p.pstride;
+                constexpr int NT = kCoefFinishGroups;
+                unsigned off[NT];
+                bool on[NT];
+                unsigned long long v[NT][3];
+#pragma unroll
+                for (int u = 0; u < NT; ++u) {
+                    const bool have = u < nt;
+                    const int uu = have ? u : 0;
+                    const bool isrow = uu < nt - t;
+                    const unsigned tile = isrow ? (unsigned)((t + uu) * p.pld + t) : (unsigned)(t * p.pld + (uu - (nt - t)));
+                    off[u] = tile * 384u + (isrow ? 0u : 192u) + (unsigned)l;
+                    on[u] = have;
+                }
+                unsigned iters = 0;
+                RES_STAMP(k, 3);
+                const bool ok = res_poll_terms<NT>(Pk, off, on, v, p.flags, iters);
+                RES_STAMP(k, 0);
+                if (p.stamps && tid == 0) p.stamps[((size_t)role * (kResMaxSweeps + 1) + k) * 4 + 2] = iters;
+                if (!ok) return;
+                {
+#pragma clang fp contract(off)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        double acc = 0.0;
+#pragma unroll
+                        for (int g = 0; g < NT; ++g) {
+                            double part = 0.0;
+                            part += on[g] ? __longlong_as_double((long long)v[g][q]) : 0.0;
+                            part += 0.0;
+                            part += 0.0;
+                            part += 0.0;
+                            acc += part;
+                        }
+                        s[q] = acc;
+                    }
+                }
+                f.sp.w_new = p.w_new[k - 1];
+                f.sp.w_old = p.w_old[k - 1];
+                const double aux[3] = {0.0, 0.0, 0.0};
+                double m_new[3], e_new[3];
+                coef_epilogue<kSweepJacobi>(f, t, i, l, s, al, fl, mu, es, aux, m_new, e_new, k == p.niter);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    mu[q] = m_new[q];
+                    eind[q] = e_new[q];
+                }
+                // the re-arming stores of the previous sweep are complete before anybody can learn mu(k) from here
+                __builtin_amdgcn_s_waitcnt(0);
+                if (k < p.niter && !(p.fault && t == 0 && k == 1)) {
+                    smu[0 * 64 + l] = mu[0];
+                    smu[1 * 64 + l] = mu[1];
+                    smu[2 * 64 + l] = mu[2];
+                    double *dst = p.pub + (size_t)k * p.slab + 192 * t;
+                    st_agent16(dst + 2 * l, smu[2 * l], smu[2 * l + 1]);
+                    if (l < 32) st_agent16(dst + 128 + 2 * l, smu[128 + 2 * l], smu[128 + 2 * l + 1]);
+                }
+                RES_STAMP(k, 1);
+#pragma unroll
+                for (int e = 0; e < NT; ++e) {
+                    if (!on[e]) continue;
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) st_agent_u64(Pk + off[e] + 64 * q, kGsSentinel);
+                }
+            }
+            if (p.palmo) {
+                f.out = p.efchg;
+                f.sp.w_new = 1.0;
+                f.sp.w_old = 0.0;
+                f.sp.want_rrms = 0;
+                double m_new[3], e_new[3];
+                coef_epilogue<kSweepPalmo>(f, t, i, l, s, al, fl, mu, es, eind, m_new, e_new);
+            }
+            return;
+        }
         for (int k = 1; k <= p.niter; ++k) {
             double *Pk = p.P + (size_t)(k & 1) * p.pstride;
             // this wave's term groups g = w, w + 4, w + 8, w + 12; group g adds the terms u = g + 16 j, j = 0..3
@@ -226,8 +307,11 @@ __global__ __launch_bounds__(kResThreads, 1) void jacobi_resident_kernel(Residen
                     on[gi * 4 + j] = have;
                 }
             }
-            const bool ok = res_poll_terms<NT>(Pk, off, on, v, p.flags);
+            unsigned iters = 0;
+            RES_STAMP(k, 3);
+            const bool ok = res_poll_terms<NT>(Pk, off, on, v, p.flags, iters);
             RES_STAMP(k, 0);
+            if (p.stamps && tid == 0) p.stamps[((size_t)role * (kResMaxSweeps + 1) + k) * 4 + 2] = iters;
 #pragma unroll
             for (int gi = 0; gi < 4; ++gi) {
                 double s0 = 0.0, s1 = 0.0, s2 = 0.0;
@@ -260,7 +344,7 @@ __global__ __launch_bounds__(kResThreads, 1) void jacobi_resident_kernel(Residen
                 f.sp.w_old = p.w_old[k - 1];
                 const double aux[3] = {0.0, 0.0, 0.0};
                 double m_new[3], e_new[3];
-                coef_epilogue<kSweepJacobi>(f, t, i, l, s, al, fl, mu, es, aux, m_new, e_new);
+                coef_epilogue<kSweepJacobi>(f, t, i, l, s, al, fl, mu, es, aux, m_new, e_new, k == p.niter);
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
                     mu[q] = m_new[q];
@@ -360,8 +444,10 @@ __global__ __launch_bounds__(kResThreads, 1) void jacobi_resident_kernel(Residen
             const int blk = (rem < 192) ? L.meta[sc][0] : L.meta[sc][1];
             addr[r] = slab + 192 * blk + (rem % 192);
         }
-        const bool ok = res_poll<NR>(addr, on, v, p.flags);
+        unsigned iters = 0;
+        const bool ok = res_poll<NR>(addr, on, v, p.flags, iters);
         RES_STAMP(k, 0);
+        if (p.stamps && tid == 0) p.stamps[((size_t)role * (kResMaxSweeps + 1) + k) * 4 + 3] = iters;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             const int e = tid + kResThreads * r;

@@ -422,6 +422,8 @@ double energy_end(system_t *system) {
             s->sweep_count += t.sweep_count; s->amatrix_count += t.amatrix_count;
             s->event_pair_ms += t.event_pair_ms; s->event_pair_count += t.event_pair_count;
             s->spec_rank_redos = t.spec_rank_redos; /* cumulative in the engine */
+            s->resident_calls = t.resident_calls;
+            s->resident_fallbacks = t.resident_fallbacks;
         }
     }
     observables_t *o = system->observables;

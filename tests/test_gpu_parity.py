@@ -718,6 +718,103 @@ def test_sweep_variants_agree():
         assert np.abs(res[0]["mu"] - r["mu"]).max() <= 1e-12 * np.abs(want["mu"]).max()
 
 
+
+RESIDENT_VARIANTS = {
+    "jacobi1": dict(polar_max_iter=1),
+    "jacobi4": dict(polar_max_iter=4),
+    "gamma10": dict(polar_max_iter=10, polar_gamma=1.03),
+    "sor": dict(polar_max_iter=6, polar_sor=1, polar_gamma=0.8),
+    "esor": dict(polar_max_iter=6, polar_esor=1, polar_gamma=0.9),
+    "palmo_rrms": dict(polar_max_iter=5, polar_palmo=1, polar_rrms=1),
+    "wolf_palmo": dict(polar_max_iter=4, polar_wolf=1, polar_wolf_alpha=0.13, polar_palmo=1),
+}
+
+
+@pytest.mark.parametrize("n", [40, 320, 1024, 1700, 2200])
+def test_resident_jacobi_solver_is_bit_identical_to_the_launch_per_sweep_path(n):
+    """Views of up to 21 blocks run the whole fixed-count Jacobi-type solve as ONE launch with the coefficient tiles
+    held in registers (kernels_resident.h; 1700 / 2200 atoms exercise the 17+ block finisher).  Same operations in the
+    same order as pair_sweep_kernel + pair_finish_kernel: every output equal to the bit, through moves and restores."""
+    s = synth.s_pol(n)
+    rng0 = np.random.default_rng(n)
+    for name, flags in RESIDENT_VARIANTS.items():
+        if n > 1100 and name not in ("jacobi4", "palmo_rrms", "sor"):
+            continue
+        p = dict(temperature=77.0, polarization=1, polar_damp=2.1304, feynman_hibbs=1, feynman_hibbs_order=4)
+        p.update(flags)
+        seed = int(rng0.integers(1 << 30))
+        out = []
+        for resident in (1, 0):
+            e = engine.Engine(n)
+            e.load_system(s, p)
+            e.set_option("resident_jacobi", resident)
+            r = e.energy()
+            r.update(e.dipoles())
+            hist = []
+            rng = np.random.default_rng(seed)
+            for k in range(4):
+                m = 5 * int(rng.integers(0, n // 5))
+                e.update_atoms(m, s["pos"][m:m + 5] + rng.normal(scale=0.1, size=3))
+                hist.append(e.energy()["energy"])
+                if k % 2:
+                    e.update_atoms(m, s["pos"][m:m + 5])
+            t = e.timings()
+            e.close()
+            assert t["resident_calls"] == (5 if resident else 0) and t["resident_fallbacks"] == 0, (name, t)
+            out.append((r, hist))
+        (a, ha), (b, hb) = out
+        for k in ("energy", "polarization_energy", "dipole_rrms", "polar_iterations"):
+            assert a[k] == b[k], (name, k, a[k], b[k])
+        for k in ("mu", "ef_induced", "ef_induced_change"):
+            assert np.array_equal(a[k], b[k]), (name, k)
+        assert ha == hb, name
+
+
+def test_resident_solver_is_only_used_where_it_applies_and_falls_back_when_a_hand_off_is_lost():
+    s = synth.s_pol(1024)
+    base = dict(temperature=77.0, polarization=1, polar_damp=2.1304)
+    # not a fixed-count Jacobi-type solve, or too many iterations for its weight table, or a view beyond 21 blocks
+    for flags, n in ((dict(polar_max_iter=4, polar_gs=1), 1024), (dict(polar_max_iter=0, polar_precision=1e-6), 1024),
+                     (dict(polar_max_iter=30), 1024), (dict(polar_max_iter=4), 4096)):
+        sys_n = s if n == 1024 else synth.s_pol(n)
+        e = engine.Engine(n)
+        e.load_system(sys_n, dict(base, **flags))
+        e.energy()
+        assert e.timings()["resident_calls"] == 0, flags
+        e.close()
+    # a second context on the device: the resident kernel needs the device to itself
+    e1, e2 = engine.Engine(1024), engine.Engine(1024)
+    for e in (e1, e2):
+        e.load_system(s, dict(base, polar_max_iter=4))
+        e.energy()
+        assert e.timings()["resident_calls"] == 0
+    e2.close()
+    e1.energy()
+    assert e1.timings()["resident_calls"] == 1  # alone again
+    e1.close()
+    # a lost hand-off (test hook): the launch gives up, the call is repeated launch by launch -- same result -- and
+    # the context stays on that path
+    p = dict(base, polar_max_iter=4, polar_palmo=1)
+    ref = run_engine(s, p, vectors=True)
+    e = engine.Engine(1024)
+    e.load_system(s, p)
+    e.set_option("resident_fault", 1)
+    r = e.energy()
+    r.update(e.dipoles())
+    t = e.timings()
+    assert t["resident_calls"] == 1 and t["resident_fallbacks"] == 1
+    assert r["energy"] == ref["energy"] and np.array_equal(r["mu"], ref["mu"])
+    e.update_atoms(0, s["pos"][0:5] + 0.05)
+    e.energy()
+    assert e.timings()["resident_calls"] == 1
+    e.set_option("resident_jacobi", 1)  # switched on again by hand: the partial-sum slots have been refilled
+    r2 = e.energy()
+    e.update_atoms(0, s["pos"][0:5])
+    r3 = e.energy()
+    assert e.timings()["resident_calls"] == 3 and e.timings()["resident_fallbacks"] == 1
+    assert r3["energy"] == ref["energy"]
+    e.close()
+
 def test_ragged_sizes_and_padding():
     """n not a multiple of the tile sizes, down to a single molecule."""
     for n in (5, 63, 65, 129, 257):
@@ -745,10 +842,15 @@ def test_timings_available():
     eng = engine.Engine(1024)
     eng.load_system(s, synth.FLAGS_POL_JACOBI)
     eng.set_option("timing", 2)
+    eng.set_option("resident_jacobi", 0)  # one sweep launch per iteration
+    eng.energy()
+    t = eng.timings()
+    assert t["sweep_count"] == 10 and t["sweep_ms"] > 0 and t["amatrix_ms"] > 0 and t["total_ms"] > 0
+    eng.set_option("resident_jacobi", 1)  # the whole solve as one launch
     eng.energy()
     t = eng.timings()
     eng.close()
-    assert t["sweep_count"] == 10 and t["sweep_ms"] > 0 and t["amatrix_ms"] > 0 and t["total_ms"] > 0
+    assert t["sweep_count"] == 1 and t["sweep_ms"] > 0 and t["resident_calls"] == 1
 
 
 def test_rccl_single_rank_allreduce():
