@@ -15,7 +15,7 @@ else:
     p.update(polar_max_iter=10)
 e = engine.Engine(len(s["charge"]))
 e.load_system(s, p)
-e.set_option("resident_jacobi", 1)
+e.set_option("resident_jacobi", int(os.environ.get("RESIDENT", "1")))
 for k in range(3):
     e.energy()
 e.set_option("resident_stamps", launches)
