@@ -1299,7 +1299,10 @@ static int ensure_sym_scratch(SweepView &v) {
 // partial-sum buffers of the tiled coefficient sweep: Srow[nt][192 nt], Zcol[nt][192 nt]
 static int ensure_coef_scratch(SweepView &v, int nt) {
     const size_t ncol = 3 * (size_t)kCoefTile * nt;
-    const size_t need = 2 * ncol * nt;
+    // sized for every tile the view can grow to: a grand-canonical insertion that starts a new 64-atom block must not
+    // pay a hipFree + hipMalloc (a millisecond, with the device idle) in the middle of an energy() call
+    const size_t ntcap = (size_t)std::max(nt, v.ntld);
+    const size_t need = 2 * (3 * (size_t)kCoefTile * ntcap) * ntcap;
     if (v.symcap < need) {
         if (v.Srow) hipFree(v.Srow);
         v.Srow = v.Zcol = nullptr;
@@ -1604,7 +1607,7 @@ static int enqueue_direct(mpmc_hip_ctx *c) {
             if (!c->lrc_valid || overflow) lsel.n = 0;
             if (!c->lrc_valid || overflow || lsel.n > 0) {
                 ScopedTimer t(c, T_OTHER, sb);
-                hipLaunchKernelGGL(lj_lrc_kernel, dim3(ntile, lsel.n > 0 ? lsel.n : ntile), dim3(64), 0, sb, a, bx, lsel,
+                hipLaunchKernelGGL(lj_lrc_kernel, dim3(ntile, lsel.n > 0 ? lsel.n : ntile), dim3(64 * kLrcWaves), 0, sb, a, bx, lsel,
                                    c->d_lrcpart);
                 hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(kReduceThreads), 0, sb, c->d_lrcpart, ntile * ntile, 1,
                                    c->d_res + R_LRC);

@@ -219,10 +219,13 @@ __global__ __launch_bounds__(64 * kPairWaves) void pair_rd_es_kernel(DevAtoms a,
 // reference's cached pair_ptr->lrc.
 // Tile partials persist like the pair kernel's; an incremental pass (sel.n > 0, grid = (npad/64, sel.n))
 // redoes the tiles of the blocks whose atoms were inserted or removed.
-__global__ __launch_bounds__(64) void lj_lrc_kernel(DevAtoms a, DevBox bx, DirtyBlocks sel,
-                                                     double *__restrict__ partials) {
+// (workgroup = 8 waves on one tile, each taking 8 of the 64 column atoms: a lone wave needs ~20 us for the 64 square
+//  roots and divides of a tile, and every grand-canonical edit redoes the tiles of the edited block)
+constexpr int kLrcWaves = 8;
+__global__ __launch_bounds__(64 * kLrcWaves) void lj_lrc_kernel(DevAtoms a, DevBox bx, DirtyBlocks sel,
+                                                                 double *__restrict__ partials) {
     int I = blockIdx.y, J = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (sel.n > 0) {
         const int d = sel.blk[blockIdx.y], o = blockIdx.x;
         for (int k = 0; k < (int)blockIdx.y; ++k)
@@ -232,21 +235,24 @@ __global__ __launch_bounds__(64) void lj_lrc_kernel(DevAtoms a, DevBox bx, Dirty
     }
     double *out = partials + (size_t)(I * gridDim.x + J);
     if (J < I) {
-        if (lane == 0) out[0] = 0.0;
+        if (threadIdx.x == 0) out[0] = 0.0;
         return;
     }
     __shared__ double seps[kWave], ssig[kWave];
     __shared__ int sfl[kWave];
-    seps[lane] = a.eps[J * kWave + lane];
-    ssig[lane] = a.sig[J * kWave + lane];
-    sfl[lane] = a.flags[J * kWave + lane];
+    __shared__ double red[kLrcWaves];
+    if (wv == 0) {
+        seps[lane] = a.eps[J * kWave + lane];
+        ssig[lane] = a.sig[J * kWave + lane];
+        sfl[lane] = a.flags[J * kWave + lane];
+    }
     __syncthreads();
     const int i = I * kWave + lane;
     const double epsi = a.eps[i], sigi = a.sig[i];
     const int fli = a.flags[i];
     const double rc = bx.cutoff;
     double acc = 0.0;
-    for (int jj = 0; jj < kWave; ++jj) {
+    for (int jj = wv * (kWave / kLrcWaves); jj < (wv + 1) * (kWave / kLrcWaves); ++jj) {
         const int j = J * kWave + jj;
         const int flj = sfl[jj];
         if (!((j > i) && (fli & kValid) && (flj & kValid) && !((fli & kFrozen) && (flj & kFrozen)))) continue;
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(64) void lj_lrc_kernel(DevAtoms a, DevBox bx, Dirty
             acc += ((16.0 / 3.0) * kPI * eps * s3) * ((1.0 / 3.0) * sc9 - sc3) / bx.volume;
         }
     }
-    if (I == J) {  // self term once per atom, on the diagonal tile
+    if (I == J && wv == 0) {  // self term once per atom, on the diagonal tile
         if ((fli & kValid) && !(fli & kFrozen) && sigi != 0.0 && epsi != 0.0) {
             const double sc = fabs(sigi) / rc;
             double s3 = fabs(sigi);
@@ -280,7 +286,14 @@ __global__ __launch_bounds__(64) void lj_lrc_kernel(DevAtoms a, DevBox bx, Dirty
         }
     }
     acc = wave_sum(acc);
-    if (lane == 0) out[0] = acc;
+    if (lane == 0) red[wv] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {  // waves in order: deterministic
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < kLrcWaves; ++k) t += red[k];
+        out[0] = t;
+    }
 }
 
 // Reciprocal-space Ewald (coulombic.c:42-95): one 256-thread block per k-vector computes the
@@ -296,10 +309,22 @@ struct KVec {
 // One block; fixed-order reduction.
 __global__ __launch_bounds__(256) void ewald_self_kernel(DevAtoms a, double ewald_alpha, double *__restrict__ out) {
     double acc = 0.0;
-    for (int i = threadIdx.x; i < a.n; i += blockDim.x) {
-        if (a.flags[i] & kFrozen) continue;
-        const double q = a.q[i];
-        acc -= ewald_alpha * q * q / sqrt(kPI);
+    // eight atoms per trip, their loads issued together (one dependent load round per trip was most of this kernel's
+    // 10 us at 4096 atoms, and every grand-canonical edit launches it); same terms in the same order per thread
+    for (int i0 = threadIdx.x; i0 < a.n; i0 += 8 * blockDim.x) {
+        double q[8];
+        int fl[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * blockDim.x;
+            fl[u] = (i < a.n) ? a.flags[i] : kFrozen;
+            q[u] = (i < a.n) ? a.q[i] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (fl[u] & kFrozen) continue;
+            acc -= ewald_alpha * q[u] * q[u] / sqrt(kPI);
+        }
     }
     acc = wave_sum(acc);
     __shared__ double s[4];
