@@ -205,6 +205,8 @@ struct mpmc_hip_ctx {
     bool call_resident = false;            // the call in flight used the resident kernel
     bool force_multi_launch = false;       // while energy_end() repeats such a call
     bool res_attr_set = false;
+    int opt_fuse_moves = 1;                // "fuse_moves": the step's move is applied inside view 0's coefficient update
+    bool moves_deferred = false;           // pending moves not yet applied in the call being enqueued
     unsigned long long resident_calls = 0, resident_fallbacks = 0;
     int opt_gs_ablate = 0;                 // timing-only ablations of the chain kernel (wrong results; tools/gs_ablate.py)
     int opt_gs_stamps = 0;                 // diagnostic: time stamps inside the chain kernel (printed by the sweep)
@@ -502,7 +504,9 @@ extern "C" int mpmc_hip_set_option(mpmc_hip_ctx *c, const char *name, int value)
     else if (!strcmp(name, "resident_jacobi")) {
         c->opt_resident = value;  // 0: one sweep + one finish launch per iteration (A/B; bit-identical results)
         if (value) c->resident_off = false;
-    } else if (!strcmp(name, "resident_fault"))
+    } else if (!strcmp(name, "fuse_moves"))
+        c->opt_fuse_moves = value;  // 0: apply_moves_kernel + update_coef_kernel as two launches (A/B; bit-identical)
+    else if (!strcmp(name, "resident_fault"))
         c->opt_res_fault = value;  // test hook: the next resident launch loses a hand-off (-> fallback)
     else if (!strcmp(name, "resident_stamps"))
         c->opt_res_stamps = value;
@@ -1556,7 +1560,17 @@ static void collect_dirty_blocks(mpmc_hip_ctx *c) {
 static int enqueue_direct(mpmc_hip_ctx *c) {
     c->recip_chunks = 0;
     c->call_resident = false;
-    if (flush_moves(c)) return -1;
+    // A single-molecule move of a steady-state polarizable step is applied inside the coefficient update of view 0
+    // (update_coef_moves_kernel) instead of by a launch of its own; setup_view() falls back to the plain way whenever
+    // that update does not happen.  (Not in the Gauss-Seidel modes: their ranking kernels read the coordinates first.)
+    {
+        const mpmc_hip_params &Pm = c->par;
+        c->moves_deferred = c->opt_fuse_moves && c->pending.n > 0 && c->graph_mode == GM_DIRECT && !c->opt_graph &&
+                            !Pm.rd_only && Pm.polarization && !Pm.polar_zodid && !Pm.polar_gs && !Pm.polar_gs_ranked &&
+                            Pm.polar_precision == 0.0 && c->opt_overlap && c->opt_pair_coef && !c->all_dirty &&
+                            c->view[0].C_valid && c->view[0].pos_valid;
+    }
+    if (!c->moves_deferred && flush_moves(c)) return -1;
     if (is_timed_call(c)) hipEventRecord(c->ev_first, c->stream);
 
     const DevAtoms a = dev_atoms(c);
@@ -1569,7 +1583,7 @@ static int enqueue_direct(mpmc_hip_ctx *c) {
     // (HBM bound) runs on the main stream -- the device-side analogue of the reference starting its
     // polarization worker before the other energy terms (energy.c:108-129, :181-186).
     hipStream_t sb = c->opt_overlap ? c->stream2 : c->stream;
-    if (c->opt_overlap) hipEventRecord(c->ev_fork, c->stream);  // (the side stream's wait is issued when it is fed)
+    if (c->opt_overlap && !c->moves_deferred) hipEventRecord(c->ev_fork, c->stream);  // (the side stream's wait is issued when it is fed)
 
     const bool do_polar = !P.rd_only && P.polarization;
     // Enqueue order: the host needs ~3 us per launch and the polarization chain is the critical path, so
@@ -1674,6 +1688,7 @@ static int enqueue_direct(mpmc_hip_ctx *c) {
                 c->enqueue_side = nullptr;
                 return -1;
             }
+            if (c->moves_deferred) return fail("MPMC_HIP: internal: a deferred move was not applied");
         } else {
             HIPCHK(hipMemsetAsync(c->d_res + R_UPOL, 0, 2 * sizeof(double), c->stream));
         }

@@ -151,6 +151,68 @@ __global__ __launch_bounds__(64) void update_coef_kernel(DevAtoms a, DevBox bx, 
     }
 }
 
+// The same update with the step's MOVE applied inside the launch (one launch less at the head of every MC step's
+// dependent chain).  The moved atoms' new coordinates travel in the kernel arguments (MoveList, as for
+// apply_moves_kernel); the dirty view slots carry theirs too (DirtyMoves), so no thread reads a moved atom's position
+// from memory: workgroup (0, 0) can write the coordinate arrays (configuration + view 0) while the others compute.
+// Same function of the same coordinates => same bits as apply_moves_kernel followed by update_coef_kernel.
+constexpr int kMaxDirtyMoves = 16;
+struct DirtyMoves {
+    int n;
+    int slot[kMaxDirtyMoves];
+    double x[kMaxDirtyMoves], y[kMaxDirtyMoves], z[kMaxDirtyMoves];
+};
+__global__ __launch_bounds__(64) void update_coef_moves_kernel(DevAtoms a, DevBox bx, double damp, DirtyMoves dm, int ntld,
+                                                                double2 *__restrict__ C, MoveList m,
+                                                                double *__restrict__ gx, double *__restrict__ gy,
+                                                                double *__restrict__ gz,
+                                                                const int *__restrict__ slot_of_atom, double *px, double *py,
+                                                                double *pz) {
+    if (blockIdx.x == 0 && blockIdx.y == 0 && (int)threadIdx.x < m.n) {  // apply_moves_kernel's stores
+        const int e = threadIdx.x, at = m.idx[e];
+        gx[at] = m.x[e];
+        gy[at] = m.y[e];
+        gz[at] = m.z[e];
+        const int s = slot_of_atom[at];
+        if (s >= 0) {  // (px / py / pz alias a.x / a.y / a.z: nobody reads a moved slot from memory in this launch)
+            px[s] = m.x[e];
+            py[s] = m.y[e];
+            pz[s] = m.z[e];
+        }
+    }
+    const int sa = dm.slot[blockIdx.y];
+    const int k = blockIdx.x * 64 + threadIdx.x;
+    if (k == sa) return;
+    double xa = dm.x[blockIdx.y], ya = dm.y[blockIdx.y], za = dm.z[blockIdx.y];
+    double xk = a.x[k], yk = a.y[k], zk = a.z[k];
+    for (int q = 0; q < dm.n; ++q) {  // a partner that moved too (same molecule): its new position
+        if (dm.slot[q] == k) {
+            xk = dm.x[q];
+            yk = dm.y[q];
+            zk = dm.z[q];
+        }
+    }
+    const int ta = sa >> 6, la = sa & 63, tk = k >> 6, lk = k & 63;
+    const bool a_is_row = (ta < tk) || (ta == tk);
+    const int i = a_is_row ? sa : k, j = a_is_row ? k : sa;
+    double c3 = 0.0, c5 = 0.0, dx, dy, dz;
+    if ((a.flags[i] & kValid) && (a.flags[j] & kValid)) {
+        if (a_is_row) thole_coef(bx, damp, xa - xk, ya - yk, za - zk, c3, c5, dx, dy, dz);
+        else thole_coef(bx, damp, xk - xa, yk - ya, zk - za, c3, c5, dx, dy, dz);
+    }
+    const double2 v = make_double2(c3, c5);
+    const size_t tsz = kCoefTile * kCoefTile;
+    if (ta < tk) {
+        C[coef_tile_index(ta, tk, ntld) * tsz + ((lk - la) & 63) * 64 + la] = v;
+    } else if (ta > tk) {
+        C[coef_tile_index(tk, ta, ntld) * tsz + ((la - lk) & 63) * 64 + lk] = v;
+    } else {
+        double2 *tile = C + coef_tile_index(ta, ta, ntld) * tsz;
+        tile[((lk - la) & 63) * 64 + la] = v;
+        tile[((la - lk) & 63) * 64 + lk] = v;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // The sweep.  grid = nt (nt + 1) / 2 workgroups, one per tile of the upper triangle (long rows
 // first); block = 256: wave w takes steps 16 w .. 16 w + 15, its 16 coefficient loads (16 B per

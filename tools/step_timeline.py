@@ -26,3 +26,7 @@ for s, e, name, q in rows[lo:hi + 1]:
 # step-to-step period
 per = [(rows[ends[k + 1]][1] - rows[ends[k]][1]) / 1e3 for k in range(max(1, which - 50), min(len(ends) - 1, which + 50))]
 print("mean step period around it: %.1f us" % (sum(per) / len(per)))
+chain = [(rows[ends[k]][1] - rows[ends[k - 1] + 1][0]) / 1e3 for k in range(max(2, which - 100), min(len(ends), which + 100))]
+chain.sort()
+print("device chain (first kernel start -> publish end) over %d steps: median %.1f us, mean %.1f us, kernels per step %.1f" %
+      (len(chain), chain[len(chain) // 2], sum(chain) / len(chain), (ends[-1] - ends[0]) / max(1, len(ends) - 1)))
