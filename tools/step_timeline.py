@@ -13,6 +13,10 @@ for f in files:
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?")))
 rows.sort()
 ends = [i for i, r in enumerate(rows) if "publish_result_kernel" in r[2]]
+if len(ends) < 10:  # the last finish launch publishes: a step ends with the finish launch that is followed by a new step's
+    # first kernel (update_coef_moves / apply_moves / apply_edits)
+    firsts = ("update_coef_moves_kernel", "apply_moves_kernel", "apply_edits_kernel")
+    ends = [i - 1 for i, r in enumerate(rows) if i > 0 and any(f in r[2] for f in firsts) and "pair_finish_kernel" in rows[i - 1][2]]
 lo, hi = ends[which - 1] + 1, ends[which]
 t0 = rows[lo][0]
 prev_end = rows[lo][0]
