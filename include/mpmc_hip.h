@@ -118,7 +118,8 @@ int mpmc_hip_create(mpmc_hip_ctx **ctx, int device, int max_atoms);
 void mpmc_hip_destroy(mpmc_hip_ctx *ctx);
 
 /* Engine knobs, for A/B measurement.  None changes what is computed; "pair_coefficients" and
- * "symmetric_sweep" change the rounding of the sweep sums (1e-15 relative), the others are bit-neutral.
+ * "symmetric_sweep" change the rounding of the sweep sums (1e-15 relative), the others are bit-neutral
+ * (tests/test_gpu_parity.py compares them bit for bit).
  *   "pair_coefficients"   (default 1): Jacobi/SOR/ESOR/Palmo sweeps run on {c3, c5} per pair (16 B) with the
  *                          geometry rebuilt in registers; 0 = on the expanded (3N)^2 A matrix (72 B per pair);
  *   "incremental_amatrix" (default 1): after mpmc_hip_update_atoms() rewrite only the entries (coefficients,
@@ -140,6 +141,18 @@ void mpmc_hip_destroy(mpmc_hip_ctx *ctx);
  *   "speculative_ranking" (default 1): polar_gs_ranked calls are enqueued for the ranked walk of the previous call
  *                          and checked on the device (repeated with the host sorting when the metric changed);
  *                          0 = the host sorts the ranking metric in every call;
+ *   "resident_jacobi"     (default 1): fixed-count Jacobi / SOR / ESOR / Palmo solves of views of up to 21 blocks
+ *                          (1 344 polarizable sites) run as ONE launch with the coefficient tiles held in registers
+ *                          (jacobi_resident_kernel); a launch that gives up on a hand-off (device shared with another
+ *                          process) makes energy_end() repeat the call launch by launch and keeps the context there
+ *                          (mpmc_hip_timings.resident_fallbacks); 0 = one sweep + one finish launch per iteration;
+ *   "sweep_alternate"     (default 1): pair_sweep_kernel walks each XCD's tiles forwards / backwards in alternate sweeps;
+ *   "sweep_nt"            (default -1): coefficient loads of the sweep non-temporal (1), default policy (0), or
+ *                          non-temporal only when the tile set exceeds the Infinity Cache (-1);
+ *   "fuse_moves"          (default 1): a single-molecule move is applied inside the coefficient update of the step
+ *                          (update_coef_moves_kernel) instead of by a launch of its own;
+ *   "resident_stamps" / "sweep_ablate": diagnostics (in-kernel time line of the resident launch; timing-only ablations
+ *                          of the sweep: results are wrong); "resident_fault": test hook (a lost hand-off);
  *   "gs_stamps"           diagnostic: the next `value` Gauss-Seidel sweeps print in-kernel time stamps per block;
  *   "gs_fault_sweep"      test hook: in sweep number `value` of a call one block is never published (the call must
  *                          fail with a hand-off error, tests/test_gpu_parity.py);

@@ -815,6 +815,39 @@ def test_resident_solver_is_only_used_where_it_applies_and_falls_back_when_a_han
     assert r3["energy"] == ref["energy"]
     e.close()
 
+
+def test_sweep_and_move_options_are_bit_neutral():
+    """sweep_alternate / sweep_nt / fuse_moves change how the step is executed, not one bit of what it computes."""
+    s = load("pcn61_bssp_4096") if os.path.exists(os.path.join(GOLD, "pcn61_bssp_4096.npz")) else synth.s_pol(2048)
+    n = len(s["charge"])
+    p = dict(temperature=77.0, polarization=1, polar_damp=2.1304, polar_max_iter=4, pbc_cutoff=8.0, feynman_hibbs=1,
+             feynman_hibbs_order=4, polar_palmo=1)
+    movable = np.where(~s["frozen"].astype(bool))[0]
+    ref = None
+    for opts in ({}, {"sweep_alternate": 0}, {"sweep_nt": 1}, {"fuse_moves": 0}, {"sweep_alternate": 0, "fuse_moves": 0,
+                                                                                   "sweep_nt": 0}):
+        e = engine.Engine(n)
+        e.load_system(s, p)
+        for k, v in opts.items():
+            e.set_option(k, v)
+        hist = [e.energy()["energy"]]
+        rng = np.random.default_rng(11)
+        for step in range(6):
+            a = int(rng.choice(movable))
+            idx = np.where(s["molecule"] == s["molecule"][a])[0]
+            first, cnt = int(idx[0]), len(idx)
+            e.update_atoms(first, s["pos"][first:first + cnt] + rng.normal(scale=0.1, size=3))
+            hist.append(e.energy()["energy"])
+            if step % 2:
+                e.update_atoms(first, s["pos"][first:first + cnt])
+        mu = e.dipoles()["mu"]
+        e.close()
+        if ref is None:
+            ref = (hist, mu)
+        else:
+            assert hist == ref[0], opts
+            assert np.array_equal(mu, ref[1]), opts
+
 def test_ragged_sizes_and_padding():
     """n not a multiple of the tile sizes, down to a single molecule."""
     for n in (5, 63, 65, 129, 257):
