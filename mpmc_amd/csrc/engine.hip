@@ -205,6 +205,7 @@ struct mpmc_hip_ctx {
     bool call_resident = false;            // the call in flight used the resident kernel
     bool force_multi_launch = false;       // while energy_end() repeats such a call
     bool res_attr_set = false;
+    unsigned res_zero_mask = 0;            // result slots the publish kernel writes as zero in the call being enqueued
     int opt_fuse_moves = 1;                // "fuse_moves": the step's move is applied inside view 0's coefficient update
     bool moves_deferred = false;           // pending moves not yet applied in the call being enqueued
     unsigned long long resident_calls = 0, resident_fallbacks = 0;
@@ -1454,7 +1455,9 @@ static int ensure_view_resident(mpmc_hip_ctx *c, SweepView &v) {
 __global__ void publish_result_kernel(double *__restrict__ d_res, volatile double *__restrict__ h_res, int n,
                                       double seq, const double *__restrict__ energy_part, int nt, int n_total,
                                       const unsigned *__restrict__ gs_err0, const unsigned *__restrict__ gs_err1,
-                                      const double *__restrict__ recip_chunk, int nrecip) {
+                                      const double *__restrict__ recip_chunk, int nrecip, unsigned zero_mask) {
+    // terms this call does not compute (no long-range correction, Wolf instead of Ewald, no polarization) are zero
+    if ((int)threadIdx.x < n && ((zero_mask >> threadIdx.x) & 1u)) d_res[threadIdx.x] = 0.0;
     if (nrecip > 0) {  // reciprocal-space sum: chunk sums in chunk order
         double e = 0.0;
         for (int t = threadIdx.x; t < nrecip; t += 64) e += recip_chunk[t];
@@ -1527,7 +1530,7 @@ static int launch_publish(mpmc_hip_ctx *c, bool do_polar) {
                        do_polar ? c->energy_nt : 0, c->n_valid,
                        c->gs_used[0] ? (const unsigned *)(c->view[0].gsflags + 1) : (const unsigned *)nullptr,
                        c->gs_used[1] ? (const unsigned *)(c->view[1].gsflags + 1) : (const unsigned *)nullptr,
-                       (const double *)c->d_recipsum, c->recip_chunks));
+                       (const double *)c->d_recipsum, c->recip_chunks, c->res_zero_mask));
     return 0;
 }
 
@@ -1559,6 +1562,7 @@ static void collect_dirty_blocks(mpmc_hip_ctx *c) {
 // One evaluation, launch by launch (also what stream capture records for the step graph).
 static int enqueue_direct(mpmc_hip_ctx *c) {
     c->recip_chunks = 0;
+    c->res_zero_mask = 0;
     c->call_resident = false;
     // A single-molecule move of a steady-state polarizable step is applied inside the coefficient update of view 0
     // (update_coef_moves_kernel) instead of by a launch of its own; setup_view() falls back to the plain way whenever
@@ -1582,8 +1586,11 @@ static int enqueue_direct(mpmc_hip_ctx *c) {
     // ---- fork: LJ / Ewald kernels (fp64-VALU bound) run on stream2 while the polarization chain
     // (HBM bound) runs on the main stream -- the device-side analogue of the reference starting its
     // polarization worker before the other energy terms (energy.c:108-129, :181-186).
-    hipStream_t sb = c->opt_overlap ? c->stream2 : c->stream;
-    if (c->opt_overlap && !c->moves_deferred) hipEventRecord(c->ev_fork, c->stream);  // (the side stream's wait is issued when it is fed)
+    // (without polarization there is nothing to overlap with: one stream, and no fork / join events -- a cross-stream
+    //  dependency costs several microseconds each way, a quarter of an LJ-only step)
+    const bool two_streams = c->opt_overlap && !P.rd_only && P.polarization;
+    hipStream_t sb = two_streams ? c->stream2 : c->stream;
+    if (two_streams && !c->moves_deferred) hipEventRecord(c->ev_fork, c->stream);  // (the side stream's wait is issued when it is fed)
 
     const bool do_polar = !P.rd_only && P.polarization;
     // Enqueue order: the host needs ~3 us per launch and the polarization chain is the critical path, so
@@ -1591,14 +1598,14 @@ static int enqueue_direct(mpmc_hip_ctx *c) {
     // ~40 us of work queued), then the side-stream kernels, then the remaining sweeps (option "side_after":
     // after 1, 2 and 3 sweeps measured 5 910 / 5 820 / 5 750 steps/s, within box noise); in precision mode
     // the chain synchronises with the host every iteration, so the side stream is fed first.
-    const bool polar_first = do_polar && c->opt_overlap && P.polar_precision == 0.0;
+    const bool polar_first = do_polar && two_streams && P.polar_precision == 0.0;
     int side_rc = 0;
     bool side_done = false;
     auto enqueue_side = [&]() {
         if (side_done) return;
         side_done = true;
         side_rc = [&]() -> int {
-        if (c->opt_overlap) hipStreamWaitEvent(sb, c->ev_fork, 0);  // after apply_moves: the new coordinates are in place
+        if (two_streams) hipStreamWaitEvent(sb, c->ev_fork, 0);  // after apply_moves: the new coordinates are in place
         // ---- LJ long-range correction: parameters + volume only => cached (lj.c:56-107)
         if (P.rd_lrc) {
             // depends on parameters, the volume and WHICH atoms exist -- not on coordinates: summed once, its
@@ -1629,7 +1636,7 @@ static int enqueue_direct(mpmc_hip_ctx *c) {
             }
             c->lrc_dirty_atoms.clear();
         } else {
-            HIPCHK(hipMemsetAsync(c->d_res + R_LRC, 0, sizeof(double), sb));
+            c->res_zero_mask |= 1u << R_LRC;  // (zeroed by the publish kernel: a memset is a launch of its own)
             c->lrc_valid = false;
         }
 
@@ -1663,7 +1670,7 @@ static int enqueue_direct(mpmc_hip_ctx *c) {
                                    c->nk, ntile, c->d_sfpart, c->d_recipsum);
                 c->recip_chunks = (c->nk + 63) / 64;
             } else {
-                HIPCHK(hipMemsetAsync(c->d_res + R_RECIP, 0, sizeof(double), sb));
+                c->res_zero_mask |= 1u << R_RECIP;
             }
             // depends on the charges and alpha only: summed at upload / edit / parameter change, then kept in d_res
             if (!c->self_valid || c->self_alpha != c->ewald_alpha) {
@@ -1672,10 +1679,10 @@ static int enqueue_direct(mpmc_hip_ctx *c) {
                 c->self_alpha = c->ewald_alpha;
             }
         } else {
-            HIPCHK(hipMemsetAsync(c->d_res + R_RECIP, 0, 2 * sizeof(double), sb));
+            c->res_zero_mask |= (1u << R_RECIP) | (1u << R_SELF);
             c->self_valid = false;
         }
-        if (c->opt_overlap) hipEventRecord(c->ev_join, sb);
+        if (two_streams) hipEventRecord(c->ev_join, sb);
         return 0;
         }();
     };
@@ -1690,7 +1697,7 @@ static int enqueue_direct(mpmc_hip_ctx *c) {
             }
             if (c->moves_deferred) return fail("MPMC_HIP: internal: a deferred move was not applied");
         } else {
-            HIPCHK(hipMemsetAsync(c->d_res + R_UPOL, 0, 2 * sizeof(double), c->stream));
+            c->res_zero_mask |= (1u << R_UPOL) | (1u << R_RRMS);
         }
         // the resident A only tracks moves while it is being maintained
         if (!do_polar || P.polar_zodid) c->view[0].A_valid = c->view[0].C_valid = false;
@@ -1698,7 +1705,7 @@ static int enqueue_direct(mpmc_hip_ctx *c) {
     c->enqueue_side = nullptr;
     enqueue_side();
     if (side_rc) return -1;
-    if (c->opt_overlap) hipStreamWaitEvent(c->stream, c->ev_join, 0);
+    if (two_streams) hipStreamWaitEvent(c->stream, c->ev_join, 0);
     const bool timed_call = is_timed_call(c);
     if (timed_call) hipEventRecord(c->ev_last, c->stream);
     if (launch_publish(c, do_polar)) return -1;
