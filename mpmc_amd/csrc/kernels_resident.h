@@ -4,18 +4,24 @@
 //
 // The multi-launch path (pair_sweep_kernel + pair_finish_kernel per iteration) reads every 64-KB coefficient tile from
 // HBM once per sweep: n_iter x 16 B per pair.  The coefficients do not change during a solve and the chip's register
-// files hold 128 MB, so here each tile is read ONCE per energy() and kept: a tile workgroup (256 threads) owns up to
-// three tiles, 16 double2 per lane and tile (192 VGPRs), and runs all sweeps on them; only dipoles and partial sums
-// (1.5 KB per block, 3 KB per tile and sweep) travel between workgroups, through L2 / MALL.
+// files hold 128 MB, so here each tile is read ONCE per energy() and kept: a tile workgroup (256 threads) owns K tiles,
+// 16 double2 per lane and tile, and runs all sweeps on them; only dipoles and partial sums (1.5 KB per block, 3 KB per
+// tile and sweep) travel between workgroups, through L2 / MALL.  The engine uses K = 1, one workgroup per CU: views of up
+// to 21 blocks (nt + nt (nt + 1) / 2 <= 256).  K = 2 .. 5 work (the template parameter; bit-identical) and were measured
+// slower than the launch-per-sweep path at the sizes that need them -- DESIGN.md section 3 has the numbers.
 //
 // Roles (drawn from a ticket counter at start):
-//   * tile group q: tiles q, q + G, q + 2 G of the upper triangle (upper_tile_of order).  Per sweep k: poll the
+//   * tile group q: tiles q, q + G, ... of the upper triangle (upper_tile_of order).  Per sweep k: poll the
 //     dipoles mu(k-1) of its tiles' blocks, multiply (tile_quarter_product -- the same arithmetic, lane for lane, as
 //     pair_sweep_kernel), combine the four quarters through LDS in the same order, publish the tile's row / column
 //     partial sums.
 //   * finisher t (one per 64-atom block): per sweep polls the nt partial sums of its block, adds them in
 //     pair_finish_kernel's order, runs the same epilogue (coef_epilogue: new mu, SOR / ESOR mix, RRMS, energy share)
-//     and publishes mu(k) of the block.  Its old dipoles and E_induced stay in registers.
+//     and publishes mu(k) of the block.  Its old dipoles and E_induced stay in registers.  Up to 16 blocks every term
+//     group holds one term, and a single wave does all of it in registers (no LDS, no barrier).
+//     The Palmo contraction needs no further product: for Jacobi it is the last sweep's.
+// Polling loops are branch-free (all wanted values re-read back to back in every pass): with a conditional re-load per
+// value the compiler's wait placement made a pass two dependent round trips (3.9 us per hand-off instead of 1.8).
 // Results are bit-identical to the multi-launch path (same operations, same order; tests/test_gpu_parity.py).
 //
 // Hand-offs are data-is-the-flag (kernels_gs_chain.h): every double is published with an agent-scope write-through
