@@ -202,6 +202,33 @@ def test_uvt_gauss_seidel_edits_follow_the_list_order():
         h.close()
 
 
+
+def test_uvt_chain_is_the_same_with_and_without_the_resident_solver():
+    """A grand-canonical chain on a small box (the view grows and shrinks across 64-atom block boundaries) with the
+    dipole solve as one resident launch and with a launch pair per sweep: bit-identical results mean the SAME chain --
+    every decision, every atom count, every energy to the last bit."""
+    s = synth.s_pol(160, spacing=4.5)
+    p = dict(temperature=77.0, polarization=1, polar_damp=2.1304, polar_max_iter=5, polar_palmo=1, feynman_hibbs=1,
+             feynman_hibbs_order=4)
+    traces = []
+    for resident in (1, 0):
+        h = host.HostSystem(s, p, seed=57, move_factor=0.05, rot_factor=0.05,
+                            extra={"ensemble": "uvt", "insert_probability": 0.7, "pressure": 400.0})
+        h.energy()  # creates the context
+        h.set_option("resident_jacobi", resident)
+        h.enable_timing(True)  # (the host layer reads the engine's counters only then)
+        tr = []
+        for _ in range(20):
+            acc = h.mc_steps(6)
+            tr.append((acc, h.natoms(), h.observables()["energy"], h.observables()["polarization_energy"]))
+        used = h.timings().get("resident_calls", 0)
+        h.close()  # one context at a time: the resident kernel wants the device to itself
+        traces.append((tr, used))
+    (a, used_a), (b, used_b) = traces
+    assert used_a > 100 and used_b <= 1  # (the call that created the second context ran before the option was set)
+    assert len({t[1] for t in a}) > 2, "N hardly changed"
+    assert a == b
+
 def test_uvt_chain_without_polarization():
     """Grand-canonical chain of charged LJ dimers (no polarization): insertions / removals only touch the pair
     tiles, the reciprocal-space block partials, the long-range-correction tiles and the cached self term."""
