@@ -435,7 +435,7 @@ __device__ __forceinline__ void tile_quarter_product(const double2 (&c)[kCoefSte
         zx = fma(wi, dx, fma(c3, mix, zx));
         zy = fma(wi, dy, fma(c3, miy, zy));
         zz = fma(wi, dz, fma(c3, miz, zz));
-        // TIGHT: the scheduler may not move work across steps (the resident solver holds three tiles in registers and has
+        // TIGHT: the scheduler may not move work across steps (a resident workgroup holding three or more tiles has
         // ~60 VGPRs for everything else; hoisting the LDS reads of later steps costs more registers than it has)
         if (TIGHT) __builtin_amdgcn_sched_barrier(0);
     }

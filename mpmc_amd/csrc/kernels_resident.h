@@ -146,15 +146,6 @@ __device__ __forceinline__ bool res_poll_terms(const double *base, const unsigne
     return false;
 }
 
-// a[s] with a run-time s, as selects (a dynamically indexed register array would go to scratch memory)
-template <typename T, int K>
-__device__ __forceinline__ T res_pick(const T (&a)[K], int s) {
-    T r = a[0];
-#pragma unroll
-    for (int k = 1; k < K; ++k) r = (s == k) ? a[k] : r;
-    return r;
-}
-
 // LDS of a tile group: staged operands of its K tiles and the quarter sums; a finisher uses the same bytes for its
 // term-group sums.  (dynamic, so that the host can pad the request to keep one workgroup per CU)
 template <int K>
