@@ -206,6 +206,7 @@ struct mpmc_hip_ctx {
     bool force_multi_launch = false;       // while energy_end() repeats such a call
     bool res_attr_set = false;
     unsigned res_zero_mask = 0;            // result slots the publish kernel writes as zero in the call being enqueued
+    int opt_gs_fold_finish = 1;            // "gs_fold_finish": gs_chain_kernel's workgroups do gs_finish_kernel's work for their block
     int opt_fuse_moves = 1;                // "fuse_moves": the step's move is applied inside view 0's coefficient update
     bool moves_deferred = false;           // pending moves not yet applied in the call being enqueued
     unsigned long long resident_calls = 0, resident_fallbacks = 0;
@@ -505,7 +506,9 @@ extern "C" int mpmc_hip_set_option(mpmc_hip_ctx *c, const char *name, int value)
     else if (!strcmp(name, "resident_jacobi")) {
         c->opt_resident = value;  // 0: one sweep + one finish launch per iteration (A/B; bit-identical results)
         if (value) c->resident_off = false;
-    } else if (!strcmp(name, "fuse_moves"))
+    } else if (!strcmp(name, "gs_fold_finish"))
+        c->opt_gs_fold_finish = value;  // 0: gs_finish_kernel as a launch of its own after every chain launch (A/B)
+    else if (!strcmp(name, "fuse_moves"))
         c->opt_fuse_moves = value;  // 0: apply_moves_kernel + update_coef_kernel as two launches (A/B; bit-identical)
     else if (!strcmp(name, "resident_fault"))
         c->opt_res_fault = value;  // test hook: the next resident launch loses a hand-off (-> fallback)

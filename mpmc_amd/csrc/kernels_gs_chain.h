@@ -81,6 +81,17 @@ struct GsChain {
     int ablate;        // TIMING-ONLY ablations (option "gs_ablate", results are wrong): bit 0 no source loop, bit 1 no
                        // tile loads, bit 2 no polls in the source loop, bit 3 the critical section only republishes
     unsigned long long *stamps;  // diagnostic (option "gs_stamps"): [nb][16] s_memrealtime stamps of one sweep, or null
+    // End-of-sweep bookkeeping of the block (what gs_finish_kernel does as a launch of its own: E_induced, the (S)OR mix,
+    // RRMS, max change), done by the block's workgroup AFTER it has published -- off the chain's critical path.
+    struct Finish {
+        int on;
+        const int *flags;
+        const double *mu_old;
+        double w_new, w_old;
+        int want_rrms, err_slot;  // err_slot < 0: no convergence measure wanted
+        double *mu_out, *mu_new_lin, *ef_induced, *rrms;
+        unsigned long long *errmax;
+    } fin;
 };
 
 // offset of column / row j in a packed strict triangle of a 64-atom block: j 63 - j (j - 1) / 2
@@ -572,10 +583,53 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
     }
     GS_STAMP(11);
     if (p.stamps && tid == 0) p.stamps[(size_t)t * 16 + 13] = __builtin_amdgcn_s_memtime();
+    double dd = 0.0, nn = 0.0;
     if (tid < 192) {
         // E_induced of the atom when it was updated (thole_iterative.c:44-46): mu = alpha (e + E_ind)
         const int k = 64 * t + lane;
-        p.y[3 * k + w] = (f_al != 0.0) ? smu[w * 64 + lane] / f_al - f_es : 0.0;
+        const double mu_c = smu[w * 64 + lane];
+        const double eind = (f_al != 0.0) ? mu_c / f_al - f_es : 0.0;
+        p.y[3 * k + w] = eind;
+        if (p.fin.on) {  // gs_finish_kernel's per-component part (thole_iterative.c:61-117, :238-252)
+            const bool polar = (f_al != 0.0) && (p.fin.flags[k] & kValid);
+            const double nw = polar ? mu_c : 0.0;
+            const double old = p.fin.mu_old[3 * k + w];
+            p.fin.mu_new_lin[3 * k + w] = nw;
+            p.fin.ef_induced[3 * k + w] = polar ? eind : 0.0;
+            p.fin.mu_out[3 * k + w] = polar ? (p.fin.w_new * nw + p.fin.w_old * old) : 0.0;
+            const double d = nw - old;
+            dd = d * d;
+            nn = nw * nw;
+        }
+    }
+    if (p.fin.on && (p.fin.want_rrms || p.fin.err_slot >= 0)) {
+        // per-atom sums over the three components (held by three different waves): through zred, which is free now
+        if (tid < 192) {
+            zred[w * 64 + lane] = dd;
+            zred[(3 + w) * 64 + lane] = nn;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int k = 64 * t + lane;
+            double d2 = 0.0, n2 = 0.0, emax = 0.0;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const double x = zred[q * 64 + lane];
+                d2 += x;
+                n2 += zred[(3 + q) * 64 + lane];
+                emax = fmax(emax, x);
+            }
+            const bool valid = p.fin.flags[k] & kValid;
+            if (p.fin.want_rrms) {
+                double rr = sqrt(d2 / n2);
+                if (!isfinite(rr)) rr = 0.0;
+                p.fin.rrms[k] = valid ? rr : 0.0;
+            }
+            if (p.fin.err_slot >= 0) {
+                emax = wave_max(valid ? emax : 0.0);
+                if (lane == 0) atomicMax(p.fin.errmax + p.fin.err_slot, (unsigned long long)__double_as_longlong(emax));
+            }
+        }
     }
 }
 
