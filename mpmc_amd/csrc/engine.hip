@@ -205,6 +205,7 @@ struct mpmc_hip_ctx {
     bool call_resident = false;            // the call in flight used the resident kernel
     bool force_multi_launch = false;       // while energy_end() repeats such a call
     bool res_attr_set = false;
+    int pair_rows_to_sum = 0;              // tile partials of the pair kernel the publish kernel has to add up
     unsigned res_zero_mask = 0;            // result slots the publish kernel writes as zero in the call being enqueued
     int opt_gs_fold_finish = 1;            // "gs_fold_finish": gs_chain_kernel's workgroups do gs_finish_kernel's work for their block
     int opt_fuse_moves = 1;                // "fuse_moves": the step's move is applied inside view 0's coefficient update
@@ -1455,36 +1456,67 @@ static int ensure_view_resident(mpmc_hip_ctx *c, SweepView &v) {
 
 // the 16-double result record goes straight into mapped pinned host memory (no copy engine / copy kernel)
 // followed by a sequence number the host spins on (no dependence on the device's sync-scheduling mode)
-__global__ void publish_result_kernel(double *__restrict__ d_res, volatile double *__restrict__ h_res, int n,
-                                      double seq, const double *__restrict__ energy_part, int nt, int n_total,
-                                      const unsigned *__restrict__ gs_err0, const unsigned *__restrict__ gs_err1,
-                                      const double *__restrict__ recip_chunk, int nrecip, unsigned zero_mask) {
+__global__ __launch_bounds__(mpmc::kReduceThreads) void publish_result_kernel(
+    double *__restrict__ d_res, volatile double *__restrict__ h_res, int n, double seq,
+    const double *__restrict__ energy_part, int nt, int n_total, const unsigned *__restrict__ gs_err0,
+    const unsigned *__restrict__ gs_err1, const double *__restrict__ recip_chunk, int nrecip, unsigned zero_mask,
+    const double *__restrict__ pair_part, int pair_rows, int pair_slot) {
+    // ---- the LJ / real-space Ewald tile partials (reduce_rows_kernel's arithmetic in reduce_rows_kernel's order: this
+    // used to be a launch of its own behind the pair kernel): thread t takes rows t, t + 1024, ..., 64-lane butterflies,
+    // then the 16 wave sums in order
+    if (pair_rows > 0) {
+        __shared__ double s[mpmc::kReduceThreads / 64][4];
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int r = threadIdx.x; r < pair_rows; r += mpmc::kReduceThreads) {
+            const double *p = pair_part + (size_t)r * mpmc::kPairChannels;
+#pragma unroll
+            for (int c = 0; c < mpmc::kPairChannels; ++c) acc[c] += p[c];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            acc[c] = mpmc::wave_sum(acc[c]);
+            if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6][c] = acc[c];
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < mpmc::kPairChannels) {
+            double t = 0.0;
+#pragma unroll
+            for (int w = 0; w < mpmc::kReduceThreads / 64; ++w) t += s[w][threadIdx.x];
+            d_res[pair_slot + threadIdx.x] = t;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x >= 64) return;  // the record itself is one wave's work
     // terms this call does not compute (no long-range correction, Wolf instead of Ewald, no polarization) are zero
     if ((int)threadIdx.x < n && ((zero_mask >> threadIdx.x) & 1u)) d_res[threadIdx.x] = 0.0;
+    double rec = 0.0, e = 0.0, r = 0.0;
     if (nrecip > 0) {  // reciprocal-space sum: chunk sums in chunk order
-        double e = 0.0;
-        for (int t = threadIdx.x; t < nrecip; t += 64) e += recip_chunk[t];
-        e = mpmc::wave_sum(e);
-        if (threadIdx.x == 0) d_res[R_RECIP] = e;
+        for (int t = threadIdx.x; t < nrecip; t += 64) rec += recip_chunk[t];
+        rec = mpmc::wave_sum(rec);
     }
-    // error words of the persistent Gauss-Seidel launches of this call travel with the result record
-    if (threadIdx.x == 0) d_res[R_GS_ERR] = ((gs_err0 && *gs_err0) ? 1.0 : 0.0) + ((gs_err1 && *gs_err1) ? 2.0 : 0.0);
     if (nt > 0) {
         // U_pol and <rrms> from the per-block sums the finish step left (fixed order)
-        double e = 0.0, r = 0.0;
         for (int t = threadIdx.x; t < nt; t += 64) {
             e += energy_part[2 * t];
             r += energy_part[2 * t + 1];
         }
         e = mpmc::wave_sum(e);
         r = mpmc::wave_sum(r);
-        if (threadIdx.x == 0) {
-            d_res[R_UPOL] = -0.5 * e;
-            d_res[R_RRMS] = r / (double)n_total;  // mean over ALL atoms (polar.c:21-27)
-        }
     }
-    __syncthreads();  // thread 0's additions to the record are in place before the record is copied
-    if ((int)threadIdx.x < n) h_res[threadIdx.x] = d_res[threadIdx.x];
+    // the record: what the other kernels left in d_res, with this kernel's sums in their slots (one wave: the values
+    // travel in registers, a lane's own earlier store to its slot is ordered before its load)
+    double v = 0.0;
+    if ((int)threadIdx.x < n) {
+        v = d_res[threadIdx.x];
+        if ((zero_mask >> threadIdx.x) & 1u) v = 0.0;
+        if (nrecip > 0 && threadIdx.x == R_RECIP) v = rec;
+        // error words of the persistent launches of this call travel with the result record
+        if (threadIdx.x == R_GS_ERR) v = ((gs_err0 && *gs_err0) ? 1.0 : 0.0) + ((gs_err1 && *gs_err1) ? 2.0 : 0.0);
+        if (nt > 0 && threadIdx.x == R_UPOL) v = -0.5 * e;
+        if (nt > 0 && threadIdx.x == R_RRMS) v = r / (double)n_total;  // mean over ALL atoms (polar.c:21-27)
+        d_res[threadIdx.x] = v;
+        h_res[threadIdx.x] = v;
+    }
     __threadfence_system();
     if (threadIdx.x == 0) h_res[n] = seq;
 }
@@ -1528,12 +1560,13 @@ static int launch_recip_partial(mpmc_hip_ctx *c, const DevAtoms &a, hipStream_t 
 }
 
 static int launch_publish(mpmc_hip_ctx *c, bool do_polar) {
-    HIPCHK(launch_slot(c, GS_PUBLISH, publish_result_kernel, dim3(1), dim3(64), c->stream, c->d_res, c->h_res_dev,
+    HIPCHK(launch_slot(c, GS_PUBLISH, publish_result_kernel, dim3(1), dim3(kReduceThreads), c->stream, c->d_res, c->h_res_dev,
                        (int)R_COUNT, (double)c->energy_calls, do_polar ? c->energy_part : (const double *)nullptr,
                        do_polar ? c->energy_nt : 0, c->n_valid,
                        c->gs_used[0] ? (const unsigned *)(c->view[0].gsflags + 1) : (const unsigned *)nullptr,
                        c->gs_used[1] ? (const unsigned *)(c->view[1].gsflags + 1) : (const unsigned *)nullptr,
-                       (const double *)c->d_recipsum, c->recip_chunks, c->res_zero_mask));
+                       (const double *)c->d_recipsum, c->recip_chunks, c->res_zero_mask, (const double *)c->d_pairpart,
+                       c->pair_rows_to_sum, (int)R_RD_PAIR));
     return 0;
 }
 
@@ -1647,8 +1680,7 @@ static int enqueue_direct(mpmc_hip_ctx *c) {
         {
             ScopedTimer t(c, T_PAIR, sb);
             if (launch_pair_kernel(c, a, bx, sb)) return -1;
-            hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(kReduceThreads), 0, sb, c->d_pairpart, ntile * ntile,
-                               kPairChannels, c->d_res + R_RD_PAIR);
+            c->pair_rows_to_sum = ntile * ntile;  // summed by the publish kernel (same arithmetic, one launch less)
         }
 
         // ---- reciprocal + self (absent under Wolf summation, coulombic.c:27-28)
