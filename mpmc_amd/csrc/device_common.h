@@ -48,6 +48,20 @@ struct DevBox {
 
 // SoA view of the configuration resident in HBM.  All arrays have npad entries
 // (npad = n rounded up to 64); pad atoms carry flags = 0, q = alpha = eps = sig = 0.
+// Coordinates of the atoms moved since the last energy(), by value in the kernel arguments (kernels_polar.h:
+// apply_moves_kernel; kernels_coef.h / kernels_pair.h: the kernels a move can ride in).
+constexpr int kMaxMoves = 32;
+struct MoveList {
+    int n;
+    int idx[kMaxMoves];
+    double x[kMaxMoves], y[kMaxMoves], z[kMaxMoves];
+};
+struct MoveTargets {  // where a kernel that carries the move writes it (what apply_moves_kernel writes)
+    double *x, *y, *z;
+    const int *slot_of_atom;
+    double *px, *py, *pz;
+};
+
 struct DevAtoms {
     const double *x, *y, *z;
     const double *q, *alpha, *eps, *sig, *molmass;

@@ -209,6 +209,7 @@ struct mpmc_hip_ctx {
     unsigned res_zero_mask = 0;            // result slots the publish kernel writes as zero in the call being enqueued
     int opt_gs_fold_finish = 1;            // "gs_fold_finish": gs_chain_kernel's workgroups do gs_finish_kernel's work for their block
     int opt_fuse_moves = 1;                // "fuse_moves": the step's move is applied inside view 0's coefficient update
+    bool moves_in_pair = false;            // ... or inside the pair kernel's launch (steps without polarization)
     bool moves_deferred = false;           // pending moves not yet applied in the call being enqueued
     unsigned long long resident_calls = 0, resident_fallbacks = 0;
     int opt_gs_ablate = 0;                 // timing-only ablations of the chain kernel (wrong results; tools/gs_ablate.py)
@@ -1537,12 +1538,21 @@ static int launch_pair_kernel(mpmc_hip_ctx *c, const DevAtoms &a, const DevBox &
     if (!c->pair_part_valid) sel.n = 0;
     const dim3 grid(ntile, sel.n > 0 ? sel.n : ntile), block(64 * kPairWaves);
     if (c->pair_part_valid && c->dirty_atoms.empty()) return 0;  // nothing moved since the partials were made
+    // the step's move, when this launch carries it (steps without polarization: enqueue_direct)
+    MoveList mv;
+    mv.n = 0;
+    MoveTargets mt = {c->d_x, c->d_y, c->d_z, c->view[0].d_slot, c->view[0].px, c->view[0].py, c->view[0].pz};
+    if (c->moves_in_pair && c->pending.n > 0) {
+        mv = c->pending;
+        c->pending.n = 0;
+    }
+    c->moves_in_pair = false;
     if (pp.fh_order == 0)
-        HIPCHK(launch_slot(c, GS_PAIR, pair_rd_es_kernel<0>, grid, block, sb, a, bx, pp, sel, c->d_pairpart));
+        HIPCHK(launch_slot(c, GS_PAIR, pair_rd_es_kernel<0>, grid, block, sb, a, bx, pp, sel, c->d_pairpart, mv, mt));
     else if (pp.fh_order == 2)
-        HIPCHK(launch_slot(c, GS_PAIR, pair_rd_es_kernel<2>, grid, block, sb, a, bx, pp, sel, c->d_pairpart));
+        HIPCHK(launch_slot(c, GS_PAIR, pair_rd_es_kernel<2>, grid, block, sb, a, bx, pp, sel, c->d_pairpart, mv, mt));
     else
-        HIPCHK(launch_slot(c, GS_PAIR, pair_rd_es_kernel<4>, grid, block, sb, a, bx, pp, sel, c->d_pairpart));
+        HIPCHK(launch_slot(c, GS_PAIR, pair_rd_es_kernel<4>, grid, block, sb, a, bx, pp, sel, c->d_pairpart, mv, mt));
     c->pair_part_valid = true;
     return 0;
 }
@@ -1610,7 +1620,11 @@ static int enqueue_direct(mpmc_hip_ctx *c) {
                             Pm.polar_precision == 0.0 && c->opt_overlap && c->opt_pair_coef && !c->all_dirty &&
                             c->view[0].C_valid && c->view[0].pos_valid;
     }
-    if (!c->moves_deferred && flush_moves(c)) return -1;
+    // Without polarization the pair kernel is the first kernel of the step that reads coordinates: the move rides in it.
+    // (The long-range-correction and self-term kernels in front of it read parameters only.)
+    c->moves_in_pair = !c->moves_deferred && c->opt_fuse_moves && c->pending.n > 0 && c->graph_mode == GM_DIRECT &&
+                       !c->opt_graph && !(!c->par.rd_only && c->par.polarization) && !c->dirty_atoms.empty();
+    if (!c->moves_deferred && !c->moves_in_pair && flush_moves(c)) return -1;
     if (is_timed_call(c)) hipEventRecord(c->ev_first, c->stream);
 
     const DevAtoms a = dev_atoms(c);
@@ -1740,6 +1754,8 @@ static int enqueue_direct(mpmc_hip_ctx *c) {
     c->enqueue_side = nullptr;
     enqueue_side();
     if (side_rc) return -1;
+    if (c->pending.n > 0 && flush_moves(c)) return -1;  // (a move no launch of this call carried: cannot happen, but cheap)
+    c->moves_in_pair = false;
     if (two_streams) hipStreamWaitEvent(c->stream, c->ev_join, 0);
     const bool timed_call = is_timed_call(c);
     if (timed_call) hipEventRecord(c->ev_last, c->stream);

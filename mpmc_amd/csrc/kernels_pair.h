@@ -33,11 +33,24 @@ struct JTile {
     int mol[kWave], flags[kWave];
 };
 
-__device__ __forceinline__ void load_jtile(JTile &t, const DevAtoms &a, int j0, int lane) {
+// position of atom i: from the step's move when it carries one for i, else from memory
+__device__ __forceinline__ void moved_position(const DevAtoms &a, const MoveList &m, int i, double &x, double &y,
+                                               double &z) {
+    x = a.x[i];
+    y = a.y[i];
+    z = a.z[i];
+    for (int e = 0; e < m.n; ++e) {
+        if (m.idx[e] == i) {
+            x = m.x[e];
+            y = m.y[e];
+            z = m.z[e];
+        }
+    }
+}
+
+__device__ __forceinline__ void load_jtile(JTile &t, const DevAtoms &a, const MoveList &m, int j0, int lane) {
     int j = j0 + lane;  // j < npad always (grid covers npad/64 tiles)
-    t.x[lane] = a.x[j];
-    t.y[lane] = a.y[j];
-    t.z[lane] = a.z[j];
+    moved_position(a, m, j, t.x[lane], t.y[lane], t.z[lane]);
     t.fx[lane] = (float)t.x[lane];
     t.fy[lane] = (float)t.y[lane];
     t.fz[lane] = (float)t.z[lane];
@@ -62,7 +75,23 @@ constexpr int kPairJPerWave = kWave / kPairWaves;
 template <int FH>
 __global__ __launch_bounds__(64 * kPairWaves) void pair_rd_es_kernel(DevAtoms a, DevBox bx, PairParams pp,
                                                                       DirtyBlocks sel,
-                                                                      double *__restrict__ partials) {
+                                                                      double *__restrict__ partials, MoveList m,
+                                                                      MoveTargets mt) {
+    // In a step without polarization the MC move rides in THIS launch (m.n > 0; with polarization it rides in the
+    // coefficient update): every thread takes a moved atom's position from the list, never from memory, and workgroup
+    // (0, 0) writes the coordinate arrays for the kernels behind this one.
+    if (m.n > 0 && blockIdx.x == 0 && blockIdx.y == 0 && (int)threadIdx.x < m.n) {
+        const int e = threadIdx.x, at = m.idx[e];
+        mt.x[at] = m.x[e];
+        mt.y[at] = m.y[e];
+        mt.z[at] = m.z[e];
+        const int s = mt.slot_of_atom[at];
+        if (s >= 0) {
+            mt.px[s] = m.x[e];
+            mt.py[s] = m.y[e];
+            mt.pz[s] = m.z[e];
+        }
+    }
     int I = blockIdx.y, J = blockIdx.x;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (sel.n > 0) {
@@ -79,11 +108,12 @@ __global__ __launch_bounds__(64 * kPairWaves) void pair_rd_es_kernel(DevAtoms a,
     }
     __shared__ JTile t;
     __shared__ double red[kPairWaves][3];
-    if (wv == 0) load_jtile(t, a, J * kWave, lane);
+    if (wv == 0) load_jtile(t, a, m, J * kWave, lane);
     __syncthreads();
 
     const int i = I * kWave + lane;
-    const double xi = a.x[i], yi = a.y[i], zi = a.z[i];
+    double xi, yi, zi;
+    moved_position(a, m, i, xi, yi, zi);
     const float xif = (float)xi, yif = (float)yi, zif = (float)zi;
     const double qi = a.q[i], epsi = a.eps[i], sigi = a.sig[i], mmi = a.molmass[i];
     const int moli = a.mol[i], fli = a.flags[i];

@@ -375,12 +375,7 @@ __global__ __launch_bounds__(64) void build_amatrix_kernel(DevAtoms a, DevBox bx
 // grid = (nvpad/128 [column tiles], ndirty); block = 64.
 // Coordinates of the atoms moved since the last energy(), by value in the kernel arguments: one tiny
 // launch replaces the 3-6 staged host-to-device copies (each a ~5 us copy kernel) of an MC move.
-constexpr int kMaxMoves = 32;
-struct MoveList {
-    int n;
-    int idx[kMaxMoves];
-    double x[kMaxMoves], y[kMaxMoves], z[kMaxMoves];
-};
+// (MoveList itself lives in device_common.h: the pair kernel takes one too)
 
 __global__ __launch_bounds__(64) void apply_moves_kernel(MoveList m, double *__restrict__ x, double *__restrict__ y,
                                                           double *__restrict__ z, const int *__restrict__ slot_of_atom,
