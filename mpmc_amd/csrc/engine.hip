@@ -1570,7 +1570,9 @@ static int launch_recip_partial(mpmc_hip_ctx *c, const DevAtoms &a, hipStream_t 
 }
 
 static int launch_publish(mpmc_hip_ctx *c, bool do_polar) {
-    HIPCHK(launch_slot(c, GS_PUBLISH, publish_result_kernel, dim3(1), dim3(kReduceThreads), c->stream, c->d_res, c->h_res_dev,
+    // (one wave unless the kernel also has the pair kernel's tile partials to add up)
+    HIPCHK(launch_slot(c, GS_PUBLISH, publish_result_kernel, dim3(1), dim3(c->pair_rows_to_sum > 0 ? kReduceThreads : 64),
+                       c->stream, c->d_res, c->h_res_dev,
                        (int)R_COUNT, (double)c->energy_calls, do_polar ? c->energy_part : (const double *)nullptr,
                        do_polar ? c->energy_nt : 0, c->n_valid,
                        c->gs_used[0] ? (const unsigned *)(c->view[0].gsflags + 1) : (const unsigned *)nullptr,
@@ -1694,7 +1696,14 @@ static int enqueue_direct(mpmc_hip_ctx *c) {
         {
             ScopedTimer t(c, T_PAIR, sb);
             if (launch_pair_kernel(c, a, bx, sb)) return -1;
-            c->pair_rows_to_sum = ntile * ntile;  // summed by the publish kernel (same arithmetic, one launch less)
+            if (two_streams) {
+                // beside the polarization chain the sum is free on the side stream, and would be 3.5 us of the main one
+                hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(kReduceThreads), 0, sb, c->d_pairpart, ntile * ntile,
+                                   kPairChannels, c->d_res + R_RD_PAIR);
+                c->pair_rows_to_sum = 0;
+            } else {
+                c->pair_rows_to_sum = ntile * ntile;  // summed by the publish kernel (same arithmetic, one launch less)
+            }
         }
 
         // ---- reciprocal + self (absent under Wolf summation, coulombic.c:27-28)
