@@ -400,7 +400,7 @@ __global__ __launch_bounds__(64 * kCoefFinishGroups) void pair_finish_kernel(int
         s[p] = acc;
     }
     double m_new[3], e_new[3];
-    coef_epilogue<MODE>(f, t, i, lane, s, al, fl, old, es, aux, m_new, e_new);
+    coef_epilogue<MODE>(f, t, i, lane, s, al, fl, old, es, aux, m_new, e_new, !f.sp.skip_sums);
 }
 
 // One wave's quarter (steps 16 w .. 16 w + 15) of a tile's product: row sums stay in the lane, the column sums follow

@@ -531,6 +531,7 @@ struct SweepParams {
     int want_rrms;   // polar_rrms || polar_precision > 0
     int want_err;    // polar_precision > 0: the host reads max (new-old)^2 after every sweep
     int err_slot;    // index into errmax[] for this iteration
+    int skip_sums;   // 1: the block's energy / RRMS sums are not wanted (an iteration that is known not to be the last)
 };
 
 template <int MODE>

@@ -200,6 +200,7 @@ __global__ __launch_bounds__(kResThreads, 1) void jacobi_resident_kernel(Residen
         f.sp.want_rrms = p.want_rrms;
         f.sp.want_err = 0;
         f.sp.err_slot = 0;
+        f.sp.skip_sums = 0;
         double s[3] = {0.0, 0.0, 0.0};
         if (nt <= kCoefFinishGroups) {
             // ---- up to 16 blocks: every term group holds one term, so ONE wave polls all of them (48 loads per lane in
