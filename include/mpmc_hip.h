@@ -146,6 +146,9 @@ void mpmc_hip_destroy(mpmc_hip_ctx *ctx);
  *                          (jacobi_resident_kernel); a launch that gives up on a hand-off (device shared with another
  *                          process) makes energy_end() repeat the call launch by launch and keeps the context there
  *                          (mpmc_hip_timings.resident_fallbacks); 0 = one sweep + one finish launch per iteration;
+ *   "resident_fold"       (default 16): views of up to this many blocks run that launch WITHOUT finisher workgroups
+ *                          (jacobi_folded_kernel: every tile workgroup finishes its own two blocks, one hand-off per
+ *                          sweep instead of two); 0 = a finisher workgroup per block at every size (A/B; same bits);
  *   "sweep_alternate"     (default 1): pair_sweep_kernel walks each XCD's tiles forwards / backwards in alternate sweeps;
  *   "sweep_nt"            (default -1): coefficient loads of the sweep non-temporal (1), default policy (0), or
  *                          non-temporal only when the tile set exceeds the Infinity Cache (-1);

@@ -201,6 +201,8 @@ struct mpmc_hip_ctx {
     int opt_res_fault = 0;                 // test hook: the next resident launch loses a hand-off
     int opt_res_stamps = 0;                // diagnostic: the next resident launches print their hand-off time line
     int opt_res_side = 0;                  // "resident_side": 1 = feed the LJ/Ewald stream BEFORE the resident launch
+    int opt_res_fold = 16;                 // "resident_fold": views of up to this many blocks run the solve without finisher
+                                           // workgroups (jacobi_folded_kernel); 0 = always with finishers
     bool resident_off = false;             // a resident launch gave up once: this context stays on the multi-launch path
     bool call_resident = false;            // the call in flight used the resident kernel
     bool force_multi_launch = false;       // while energy_end() repeats such a call
@@ -516,6 +518,8 @@ extern "C" int mpmc_hip_set_option(mpmc_hip_ctx *c, const char *name, int value)
         c->opt_res_fault = value;  // test hook: the next resident launch loses a hand-off (-> fallback)
     else if (!strcmp(name, "resident_stamps"))
         c->opt_res_stamps = value;
+    else if (!strcmp(name, "resident_fold"))
+        c->opt_res_fold = value;   // largest view (blocks) solved by jacobi_folded_kernel; 0 = off (A/B; bit-identical results)
     else if (!strcmp(name, "resident_side"))
         c->opt_res_side = value;   // 1: the LJ/Ewald stream is fed before the resident launch instead of after it
     else if (!strcmp(name, "pair_coefficients")) {
@@ -1387,14 +1391,17 @@ constexpr int kResidentLdsOnePerCu = 84 * 1024;  // more than half a CU's LDS: a
 constexpr int kResidentLdsMax = std::max(kResidentLdsOnePerCu, resident_lds_bytes<kResMaxK>());
 static_assert(kResidentLdsMax <= 160 * 1024, "LDS of a CU");
 typedef void (*ResidentKernel)(ResidentSolve);
-static ResidentKernel resident_kernel_of(int ortho, int K) {
+static ResidentKernel resident_kernel_of(int ortho, int K, bool fold) {
     (void)K;  // one tile per tile workgroup is the only geometry in use (see resident_plan)
+    if (fold) return ortho ? jacobi_folded_kernel<1> : jacobi_folded_kernel<0>;
     return ortho ? jacobi_resident_kernel<1, 1> : jacobi_resident_kernel<0, 1>;
 }
 static std::vector<const void *> resident_kernels() {
     std::vector<const void *> v;
-    for (int o = 0; o < 2; ++o)
-        for (int K = 1; K <= kResMaxK; ++K) v.push_back(reinterpret_cast<const void *>(resident_kernel_of(o, K)));
+    for (int o = 0; o < 2; ++o) {
+        for (int K = 1; K <= kResMaxK; ++K) v.push_back(reinterpret_cast<const void *>(resident_kernel_of(o, K, false)));
+        v.push_back(reinterpret_cast<const void *>(resident_kernel_of(o, 1, true)));
+    }
     return v;
 }
 
@@ -1403,6 +1410,7 @@ static std::vector<const void *> resident_kernels() {
 // sweep).  ok = false: does not fit (or is not a fixed-count Jacobi-type solve): the multi-launch path runs.
 struct ResidentPlan {
     bool ok = false;
+    bool fold = false;  // no finisher workgroups: every tile workgroup finishes its two blocks (jacobi_folded_kernel)
     int K = 0, ngroups = 0, lds = 0, nt = 0, ntiles = 0;
 };
 static ResidentPlan resident_plan(const mpmc_hip_ctx *c, const SweepView &v) {
@@ -1427,6 +1435,7 @@ static ResidentPlan resident_plan(const mpmc_hip_ctx *c, const SweepView &v) {
     r.nt = nt;
     r.ntiles = ntiles;
     r.ngroups = ntiles;
+    r.fold = nt <= std::min(c->opt_res_fold, kFoldMaxBlocks);
     const int need = resident_lds_bytes<1>();
     const bool one = true;
     r.lds = one ? std::max(need, kResidentLdsOnePerCu) : need;
@@ -1439,14 +1448,14 @@ static int ensure_view_resident(mpmc_hip_ctx *c, SweepView &v) {
     if (!v.resP || v.res_pld != pld) {
         if (v.resP) hipFree(v.resP);
         v.resP = nullptr;
-        HIPCHK(hipMalloc((void **)&v.resP, 2 * pstride * sizeof(double)));
+        HIPCHK(hipMalloc((void **)&v.resP, 3 * pstride * sizeof(double)));  // (two parities; three rotating buffers when folded)
         v.res_pld = pld;
         v.resP_armed = false;
     }
     if (!v.resP_armed) {
         // both 32-bit halves of the sentinel are the same word
         static_assert((kGsSentinel >> 32) == (kGsSentinel & 0xffffffffull), "sentinel halves");
-        HIPCHK(hipMemsetD32Async((hipDeviceptr_t)v.resP, (int)(kGsSentinel & 0xffffffffull), 2 * pstride * 2, c->stream));
+        HIPCHK(hipMemsetD32Async((hipDeviceptr_t)v.resP, (int)(kGsSentinel & 0xffffffffull), 3 * pstride * 2, c->stream));
         v.resP_armed = true;
     }
     if (!v.respub) HIPCHK(hipMalloc((void **)&v.respub, (size_t)kResMaxSweeps * 3 * v.cap * sizeof(double)));

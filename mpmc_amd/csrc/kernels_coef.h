@@ -255,32 +255,37 @@ struct CoefFinish {
 template <int MODE>
 __device__ __forceinline__ void coef_epilogue(const CoefFinish &f, int t, int i, int lane, const double s[3], double al,
                                               int fl, const double old[3], const double es[3], const double aux[3],
-                                              double m_out[3], double e_out[3], bool want_sums = true) {
+                                              double m_out[3], double e_out[3], bool want_sums = true,
+                                              bool store = true) {
     // (no implicit FMA contraction: the function is inlined into several kernels -- pair_finish_kernel, the
     // resident solver's finisher -- whose results are required to agree to the bit)
+    // (store = false: registers only -- the folded resident solver runs the epilogue of an intermediate sweep in every
+    //  workgroup that needs the block's new dipoles, and none of them writes the per-atom arrays)
 #pragma clang fp contract(off)
     const bool valid = fl & kValid;
     double e_i = 0.0, r_i = 0.0, emax_i = 0.0;
     m_out[0] = m_out[1] = m_out[2] = 0.0;
     e_out[0] = e_out[1] = e_out[2] = 0.0;
     if ((MODE == kSweepJacobi && (al == 0.0 || !valid)) || (MODE == kSweepPalmo && !valid)) {
+        if (store) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            f.out[3 * i + p] = 0.0;
-            if (MODE == kSweepJacobi) f.ef_induced[3 * i + p] = 0.0;
+            for (int p = 0; p < 3; ++p) {
+                f.out[3 * i + p] = 0.0;
+                if (MODE == kSweepJacobi) f.ef_induced[3 * i + p] = 0.0;
+            }
+            if (MODE == kSweepJacobi && f.sp.want_rrms) f.rrms[i] = 0.0;
         }
-        if (MODE == kSweepJacobi && f.sp.want_rrms) f.rrms[i] = 0.0;
     } else if (MODE == kSweepJacobi) {
         double d2 = 0.0, n2 = 0.0, emax = 0.0, m[3];
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             const double e = -s[p];
             const double nw = al * (es[p] + e);
-            f.ef_induced[3 * i + p] = e;
+            if (store) f.ef_induced[3 * i + p] = e;
             e_out[p] = e;
             m[p] = f.sp.w_new * nw + f.sp.w_old * old[p];
             m_out[p] = m[p];
-            f.out[3 * i + p] = m[p];
+            if (store) f.out[3 * i + p] = m[p];
             const double d = nw - old[p];
             d2 += d * d;
             n2 += nw * nw;
@@ -289,7 +294,7 @@ __device__ __forceinline__ void coef_epilogue(const CoefFinish &f, int t, int i,
         if (f.sp.want_rrms) {
             double rr = sqrt(d2 / n2);  // calc_dipole_rrms, thole_iterative.c:61-77
             if (!isfinite(rr)) rr = 0.0;
-            f.rrms[i] = rr;
+            if (store) f.rrms[i] = rr;
             r_i = rr;
         }
         emax_i = emax;

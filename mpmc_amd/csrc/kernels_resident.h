@@ -505,4 +505,242 @@ __global__ __launch_bounds__(kResThreads, 1) void jacobi_resident_kernel(Residen
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same solve WITHOUT finisher workgroups ("folded"; views of up to kFoldMaxBlocks blocks): every tile workgroup
+// finishes the two blocks it multiplies itself.  A sweep is then ONE hand-off (tile partial sums -> every workgroup
+// that touches the block) instead of two (partial sums -> finisher -> dipoles): per sweep k the workgroup of tile
+// (ti, tj)
+//   1. polls the nt partial sums of sweep k-1 that feed block ti (wave 0) and block tj (wave 1; one wave each, all
+//      terms in registers, added in pair_finish_kernel's order as the one-wave finisher above does), runs the same
+//      epilogue in registers (no stores: coef_epilogue(..., store = false)) and writes mu(k-1) of its blocks straight
+//      into the product's LDS operands (k = 1: the initial dipoles of slab 0);
+//   2. multiplies (tile_quarter_product), adds the quarters, publishes the tile's partial sums of sweep k.
+// After the last sweep the DIAGONAL tile's workgroup of each block runs the final epilogue (the one that stores the
+// per-atom results and the block's energy / RRMS sums) and the Palmo contraction.  Every workgroup touching a block
+// computes that block's dipoles with the same operations in the same order: identical bits everywhere, and the same
+// bits as the multi-launch path.
+//
+// Partial-sum slots have MANY readers here (a slot that feeds block b is read by the nt workgroups touching b), so a
+// reader cannot re-arm it.  Three rotating buffers P[k % 3]: when a workgroup has the sweep-(k-1) sums of its blocks,
+// every workgroup touching them has published sweep k-1, i.e. has finished reading the sweep-(k-2) sums -- so in sweep
+// k each workgroup re-arms ITS OWN slots of buffer (k-2) % 3 = (k+1) % 3, the buffer it writes next (same lanes, same
+// addresses, a sweep later, behind s_waitcnt vmcnt(0)).  What is left at the end -- buffers niter % 3 and
+// (niter-1) % 3 -- is re-armed by the diagonal workgroups: the final finisher of block b is the only reader of the
+// sweep-niter sums feeding b, and once it has them every reader of the sweep-(niter-1) sums feeding b is done.  So all
+// three buffers hold the sentinel between calls (after an aborted launch the host refills them, as above).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kFoldMaxBlocks = kCoefFinishGroups;  // one wave holds all terms of a block
+
+template <int ORTHO>
+__global__ __launch_bounds__(kResThreads, 1) void jacobi_folded_kernel(ResidentSolve p) {
+    extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+    __shared__ int s_role;
+    const int tid = threadIdx.x, l = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid == 0) s_role = (int)__hip_atomic_fetch_add(p.flags, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int role = __builtin_amdgcn_readfirstlane(s_role);
+    const int nt = p.nt;
+    if (role >= p.ntiles) return;
+    RES_STAMP(0, 0);
+    ResidentLds<1> &L = *reinterpret_cast<ResidentLds<1> *>(lds_raw);
+    int ti, tj;
+    upper_tile_of(role, nt, ti, tj);
+    const bool diag = ti == tj;
+    const size_t tsz = kCoefTile * kCoefTile;
+    double2 c[kCoefSteps];
+    {
+        const double2 *src = p.C + coef_tile_index(ti, tj, p.ntld) * tsz + (size_t)(kCoefSteps * w) * 64 + l;
+#pragma unroll
+        for (int k = 0; k < kCoefSteps; ++k) c[k] = stream_load_coef(src + 64 * k);
+#pragma unroll
+        for (int k = 0; k < kCoefSteps; ++k) c[k].y = -3.0 * c[k].y;
+    }
+    // the finishing waves: wave 0 -> block ti, wave 1 -> block tj (idle for a diagonal tile)
+    const bool fin = (w == 0) || (w == 1 && !diag);
+    const int tb = (w == 1) ? tj : ti;
+    const int i = 64 * tb + l;
+    double al = 0.0, mu[3] = {0.0, 0.0, 0.0}, es[3] = {0.0, 0.0, 0.0}, eind[3] = {0.0, 0.0, 0.0}, s[3] = {0.0, 0.0, 0.0};
+    int fl = 0;
+    if (fin) {
+        al = p.alpha[i];
+        fl = p.pflags[i];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            es[q] = p.es[3 * i + q];
+            mu[q] = p.pub[192 * tb + 64 * q + l];  // slab 0: the initial dipoles (init_view_kernel, the launch before)
+        }
+    }
+    if (w == 0) {
+        const int ir = 64 * ti + l, jc = 64 * tj + l;
+        L.rowv[0][0][l] = p.px[ir];
+        L.rowv[0][1][l] = p.py[ir];
+        L.rowv[0][2][l] = p.pz[ir];
+        L.jxy[0][l] = make_double2(p.px[jc], p.py[jc]);
+        L.jzm[0][l].x = p.pz[jc];
+    }
+    CoefFinish f;
+    f.alpha = p.alpha;
+    f.flags = p.pflags;
+    f.mu_in = nullptr;
+    f.es = p.es;
+    f.ef_induced = p.ef_induced;
+    f.out = p.mu_out;
+    f.rrms = p.rrms;
+    f.errmax = nullptr;
+    f.mu_final = nullptr;
+    f.energy_part = p.energy_part;
+    f.sp.want_rrms = 0;
+    f.sp.want_err = 0;
+    f.sp.err_slot = 0;
+    f.sp.skip_sums = 0;
+    // the terms of this wave's block, in the finisher's order: u < nt - tb: row sums of tile (tb, tb + u); then the
+    // column sums of tile (u - (nt - tb), tb)
+    constexpr int NT = kFoldMaxBlocks;
+    unsigned off[NT];
+    bool on[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        const bool have = u < nt;
+        const int uu = have ? u : 0;
+        const bool isrow = uu < nt - tb;
+        const unsigned tile = isrow ? (unsigned)((tb + uu) * p.pld + tb) : (unsigned)(tb * p.pld + (uu - (nt - tb)));
+        off[u] = tile * 384u + (isrow ? 0u : 192u) + (unsigned)l;
+        on[u] = have;
+    }
+    // sums of sweep kk for this wave's block -> s[]; false on a give-up
+    auto take_sums = [&](int kk) -> bool {
+        const double *Pk = p.P + (size_t)(kk % 3) * p.pstride;
+        unsigned long long v[NT][3];
+        unsigned iters = 0;
+        if (!res_poll_terms<NT>(Pk, off, on, v, p.flags, iters)) return false;
+        {
+#pragma clang fp contract(off)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                double acc = 0.0;
+#pragma unroll
+                for (int g = 0; g < NT; ++g) {
+                    double part = 0.0;
+                    part += on[g] ? __longlong_as_double((long long)v[g][q]) : 0.0;
+                    part += 0.0;
+                    part += 0.0;
+                    part += 0.0;
+                    acc += part;
+                }
+                s[q] = acc;
+            }
+        }
+        return true;
+    };
+    const size_t own = ((size_t)tj * p.pld + ti) * 384;  // this tile's slot: [6][64]
+    for (int k = 1; k <= p.niter; ++k) {
+        // ---- 1: mu(k-1) of this workgroup's blocks into the product's operands
+        bool ok = true;
+        if (fin) {
+            if (k > 1) {
+                ok = take_sums(k - 1);
+                if (ok) {
+                    f.sp.w_new = p.w_new[k - 2];
+                    f.sp.w_old = p.w_old[k - 2];
+                    const double aux[3] = {0.0, 0.0, 0.0};
+                    double m_new[3], e_new[3];
+                    coef_epilogue<kSweepJacobi>(f, tb, i, l, s, al, fl, mu, es, aux, m_new, e_new, false, false);
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) mu[q] = m_new[q];
+                }
+            }
+            if (w == 0) {
+                L.rowv[0][3][l] = mu[0];
+                L.rowv[0][4][l] = mu[1];
+                L.rowv[0][5][l] = mu[2];
+            }
+            if (w == 1 || diag) {
+                L.jzm[0][l].y = mu[0];
+                L.jmm[0][l] = make_double2(mu[1], mu[2]);
+            }
+        }
+        RES_STAMP(k, 0);
+        __syncthreads();
+        if (!ok || res_failed(p.flags)) return;  // (a wave that leaves reaches no further barrier; the others leave at
+                                                 //  this check or at their next one)
+        // ---- 2: this wave's quarter of the tile
+        {
+            double sx, sy, sz, zx, zy, zz;
+            tile_quarter_product<ORTHO, 0, 1>(c, l, w, L.rowv[0][0][l], L.rowv[0][1][l], L.rowv[0][2][l], L.rowv[0][3][l],
+                                              L.rowv[0][4][l], L.rowv[0][5][l], L.jxy[0], L.jzm[0], L.jmm[0], p.bx, sx, sy, sz,
+                                              zx, zy, zz);
+            L.red[0][w][0][l] = sx;
+            L.red[0][w][1][l] = sy;
+            L.red[0][w][2][l] = sz;
+            const int jl = (l + kCoefSteps * w + kCoefSteps - 1) & 63;
+            L.red[0][w][3][jl] = zx;
+            L.red[0][w][4][jl] = zy;
+            L.red[0][w][5][jl] = zz;
+        }
+        __builtin_amdgcn_s_waitcnt(0);  // (the re-arming stores of the previous sweep are complete before this sweep's sums leave)
+        __syncthreads();
+        RES_STAMP(k, 1);
+        // ---- 3: quarters added in pair_sweep_kernel's order; the sums leave as 16-byte write-through stores; the slot
+        // this workgroup writes NEXT sweep gets its sentinel back (its sweep-(k-2) readers are done: see the header)
+        if (tid < 192) {
+            const int vec = tid / 32, l2 = (tid & 31) * 2;
+            if (!(vec >= 3 && diag)) {  // a diagonal tile feeds rows only
+                double a = 0.0, b = 0.0;
+#pragma unroll
+                for (int q = 0; q < kCoefWaves; ++q) {
+                    a += L.red[0][q][vec][l2];
+                    b += L.red[0][q][vec][l2 + 1];
+                }
+                if (!(p.fault && role == 0 && k == 1))
+                    st_agent16(p.P + (size_t)(k % 3) * p.pstride + own + 64 * vec + l2, a, b);
+                if (k >= 3) {
+                    const double sn = __longlong_as_double((long long)kGsSentinel);
+                    st_agent16(p.P + (size_t)((k + 1) % 3) * p.pstride + own + 64 * vec + l2, sn, sn);
+                }
+            }
+        }
+        RES_STAMP(k, 2);
+        // (no barrier: red[] is rewritten only behind the next sweep's staging barrier, and the staging writes touch
+        //  operands that phase 2 -- behind the barrier above -- is done with)
+    }
+    // ---- the last epilogue: the diagonal tile's workgroup finishes its block, stores the results, re-arms what is left
+    if (!diag || w != 0) return;
+    if (!take_sums(p.niter)) return;
+    RES_STAMP(p.niter, 3);
+    f.sp.want_rrms = p.want_rrms;
+    f.sp.w_new = p.w_new[p.niter - 1];
+    f.sp.w_old = p.w_old[p.niter - 1];
+    {
+        const double aux[3] = {0.0, 0.0, 0.0};
+        double m_new[3], e_new[3];
+        coef_epilogue<kSweepJacobi>(f, ti, i, l, s, al, fl, mu, es, aux, m_new, e_new, true, true);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            mu[q] = m_new[q];
+            eind[q] = e_new[q];
+        }
+    }
+    if (p.palmo) {
+        f.out = p.efchg;
+        f.sp.w_new = 1.0;
+        f.sp.w_old = 0.0;
+        f.sp.want_rrms = 0;
+        double m_new[3], e_new[3];
+        coef_epilogue<kSweepPalmo>(f, ti, i, l, s, al, fl, mu, es, eind, m_new, e_new);
+    }
+    {
+        double *Pa = p.P + (size_t)(p.niter % 3) * p.pstride;
+        double *Pb = p.P + (size_t)((p.niter + 2) % 3) * p.pstride;  // (niter - 1) % 3
+#pragma unroll
+        for (int e = 0; e < NT; ++e) {
+            if (!on[e]) continue;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                st_agent_u64(Pa + off[e] + 64 * q, kGsSentinel);
+                if (p.niter >= 2) st_agent_u64(Pb + off[e] + 64 * q, kGsSentinel);
+            }
+        }
+    }
+}
+
 }  // namespace mpmc

@@ -730,11 +730,14 @@ RESIDENT_VARIANTS = {
 }
 
 
-@pytest.mark.parametrize("n", [40, 320, 1024, 1700, 2200])
+@pytest.mark.parametrize("n", [40, 320, 1024, 1500, 1700, 2200])
 def test_resident_jacobi_solver_is_bit_identical_to_the_launch_per_sweep_path(n):
     """Views of up to 21 blocks run the whole fixed-count Jacobi-type solve as ONE launch with the coefficient tiles
-    held in registers (kernels_resident.h; 1700 / 2200 atoms exercise the 17+ block finisher).  Same operations in the
-    same order as pair_sweep_kernel + pair_finish_kernel: every output equal to the bit, through moves and restores."""
+    held in registers (kernels_resident.h), in two forms: with a finisher workgroup per block (1700 / 2200 atoms exercise
+    the 17+ block finisher) and, up to 16 blocks, "folded" -- every tile workgroup finishes its own two blocks, three
+    rotating partial-sum buffers (the default up to 16 blocks: 56-62 us per 10-sweep solve against 65-70).  Same
+    operations in the same order as pair_sweep_kernel + pair_finish_kernel: every output equal to the bit, through moves
+    and restores, and the folded form leaves its hand-off buffers armed for the next call."""
     s = synth.s_pol(n)
     rng0 = np.random.default_rng(n)
     for name, flags in RESIDENT_VARIANTS.items():
@@ -744,10 +747,11 @@ def test_resident_jacobi_solver_is_bit_identical_to_the_launch_per_sweep_path(n)
         p.update(flags)
         seed = int(rng0.integers(1 << 30))
         out = []
-        for resident in (1, 0):
+        for resident, fold in ((1, 16), (1, 0), (0, 0)):
             e = engine.Engine(n)
             e.load_system(s, p)
             e.set_option("resident_jacobi", resident)
+            e.set_option("resident_fold", fold)
             r = e.energy()
             r.update(e.dipoles())
             hist = []
@@ -760,14 +764,15 @@ def test_resident_jacobi_solver_is_bit_identical_to_the_launch_per_sweep_path(n)
                     e.update_atoms(m, s["pos"][m:m + 5])
             t = e.timings()
             e.close()
-            assert t["resident_calls"] == (5 if resident else 0) and t["resident_fallbacks"] == 0, (name, t)
+            assert t["resident_calls"] == (5 if resident else 0) and t["resident_fallbacks"] == 0, (name, fold, t)
             out.append((r, hist))
-        (a, ha), (b, hb) = out
-        for k in ("energy", "polarization_energy", "dipole_rrms", "polar_iterations"):
-            assert a[k] == b[k], (name, k, a[k], b[k])
-        for k in ("mu", "ef_induced", "ef_induced_change"):
-            assert np.array_equal(a[k], b[k]), (name, k)
-        assert ha == hb, name
+        b, hb = out[-1]
+        for a, ha in out[:-1]:
+            for k in ("energy", "polarization_energy", "dipole_rrms", "polar_iterations"):
+                assert a[k] == b[k], (name, k, a[k], b[k])
+            for k in ("mu", "ef_induced", "ef_induced_change"):
+                assert np.array_equal(a[k], b[k]), (name, k)
+            assert ha == hb, name
 
 
 def test_resident_solver_is_only_used_where_it_applies_and_falls_back_when_a_hand_off_is_lost():
@@ -793,27 +798,29 @@ def test_resident_solver_is_only_used_where_it_applies_and_falls_back_when_a_han
     assert e1.timings()["resident_calls"] == 1  # alone again
     e1.close()
     # a lost hand-off (test hook): the launch gives up, the call is repeated launch by launch -- same result -- and
-    # the context stays on that path
+    # the context stays on that path (both forms of the kernel: folded, and with finisher workgroups)
     p = dict(base, polar_max_iter=4, polar_palmo=1)
     ref = run_engine(s, p, vectors=True)
-    e = engine.Engine(1024)
-    e.load_system(s, p)
-    e.set_option("resident_fault", 1)
-    r = e.energy()
-    r.update(e.dipoles())
-    t = e.timings()
-    assert t["resident_calls"] == 1 and t["resident_fallbacks"] == 1
-    assert r["energy"] == ref["energy"] and np.array_equal(r["mu"], ref["mu"])
-    e.update_atoms(0, s["pos"][0:5] + 0.05)
-    e.energy()
-    assert e.timings()["resident_calls"] == 1
-    e.set_option("resident_jacobi", 1)  # switched on again by hand: the partial-sum slots have been refilled
-    r2 = e.energy()
-    e.update_atoms(0, s["pos"][0:5])
-    r3 = e.energy()
-    assert e.timings()["resident_calls"] == 3 and e.timings()["resident_fallbacks"] == 1
-    assert r3["energy"] == ref["energy"]
-    e.close()
+    for fold in (16, 0):
+        e = engine.Engine(1024)
+        e.load_system(s, p)
+        e.set_option("resident_fold", fold)
+        e.set_option("resident_fault", 1)
+        r = e.energy()
+        r.update(e.dipoles())
+        t = e.timings()
+        assert t["resident_calls"] == 1 and t["resident_fallbacks"] == 1
+        assert r["energy"] == ref["energy"] and np.array_equal(r["mu"], ref["mu"])
+        e.update_atoms(0, s["pos"][0:5] + 0.05)
+        e.energy()
+        assert e.timings()["resident_calls"] == 1
+        e.set_option("resident_jacobi", 1)  # switched on again by hand: the partial-sum slots have been refilled
+        r2 = e.energy()
+        e.update_atoms(0, s["pos"][0:5])
+        r3 = e.energy()
+        assert e.timings()["resident_calls"] == 3 and e.timings()["resident_fallbacks"] == 1
+        assert r3["energy"] == ref["energy"]
+        e.close()
 
 
 def test_sweep_and_move_options_are_bit_neutral():

@@ -16,6 +16,8 @@ else:
 e = engine.Engine(len(s["charge"]))
 e.load_system(s, p)
 e.set_option("resident_jacobi", int(os.environ.get("RESIDENT", "1")))
+if os.environ.get("RESIDENT_FOLD"):
+    e.set_option("resident_fold", int(os.environ["RESIDENT_FOLD"]))  # 0 = with finisher workgroups
 for k in range(3):
     e.energy()
 e.set_option("resident_stamps", launches)
