@@ -154,6 +154,9 @@ void mpmc_hip_destroy(mpmc_hip_ctx *ctx);
  *                          non-temporal only when the tile set exceeds the Infinity Cache (-1);
  *   "fuse_moves"          (default 1): a single-molecule move is applied inside the coefficient update of the step
  *                          (update_coef_moves_kernel) instead of by a launch of its own;
+ *   "side_moves"          (default 1): in such a step the LJ / Ewald stream's pair kernel applies the same move for itself
+ *                          (both streams write the same coordinates, neither reads a moved atom from memory), so no event
+ *                          is recorded between the main stream's first two launches; 0 = fork event (A/B; same bits);
  *   "resident_stamps" / "sweep_ablate": diagnostics (in-kernel time line of the resident launch; timing-only ablations
  *                          of the sweep: results are wrong); "resident_fault": test hook (a lost hand-off);
  *   "gs_stamps"           diagnostic: the next `value` Gauss-Seidel sweeps print in-kernel time stamps per block;

@@ -213,6 +213,9 @@ struct mpmc_hip_ctx {
     int opt_fuse_moves = 1;                // "fuse_moves": the step's move is applied inside view 0's coefficient update
     bool moves_in_pair = false;            // ... or inside the pair kernel's launch (steps without polarization)
     bool moves_deferred = false;           // pending moves not yet applied in the call being enqueued
+    bool side_carry = false;               // ... and the side stream's pair kernel carries the same move itself (side_moves):
+    MoveList side_moves;                   //     no fork event between the two streams in a steady-state polarizable step
+    int opt_side_moves = 1;                // "side_moves": 0 = fork event after the main stream's move (A/B; same bits)
     unsigned long long resident_calls = 0, resident_fallbacks = 0;
     int opt_gs_ablate = 0;                 // timing-only ablations of the chain kernel (wrong results; tools/gs_ablate.py)
     int opt_gs_stamps = 0;                 // diagnostic: time stamps inside the chain kernel (printed by the sweep)
@@ -518,6 +521,8 @@ extern "C" int mpmc_hip_set_option(mpmc_hip_ctx *c, const char *name, int value)
         c->opt_res_fault = value;  // test hook: the next resident launch loses a hand-off (-> fallback)
     else if (!strcmp(name, "resident_stamps"))
         c->opt_res_stamps = value;
+    else if (!strcmp(name, "side_moves"))
+        c->opt_side_moves = value;  // 0: the side stream waits for an event recorded behind the main stream's move
     else if (!strcmp(name, "resident_fold"))
         c->opt_res_fold = value;   // largest view (blocks) solved by jacobi_folded_kernel; 0 = off (A/B; bit-identical results)
     else if (!strcmp(name, "resident_side"))
@@ -1554,7 +1559,15 @@ static int launch_pair_kernel(mpmc_hip_ctx *c, const DevAtoms &a, const DevBox &
     if (c->moves_in_pair && c->pending.n > 0) {
         mv = c->pending;
         c->pending.n = 0;
+    } else if (c->side_carry && sb == c->stream2 && c->side_moves.n > 0) {
+        // A steady-state polarizable step: the main stream applies the move inside its coefficient update
+        // (update_coef_moves_kernel) and this launch -- the first of the side stream that reads coordinates -- applies the
+        // SAME move for itself: no thread of either kernel reads a moved atom's position from memory, both write the same
+        // bits into the coordinate arrays, and each stream's later kernels come behind their own stream's writer.  So the
+        // two streams need no fork event (recording one costs the main stream ~5 us between its first two launches).
+        mv = c->side_moves;
     }
+    c->side_moves.n = 0;
     c->moves_in_pair = false;
     if (pp.fh_order == 0)
         HIPCHK(launch_slot(c, GS_PAIR, pair_rd_es_kernel<0>, grid, block, sb, a, bx, pp, sel, c->d_pairpart, mv, mt));
@@ -1636,6 +1649,10 @@ static int enqueue_direct(mpmc_hip_ctx *c) {
     c->moves_in_pair = !c->moves_deferred && c->opt_fuse_moves && c->pending.n > 0 && c->graph_mode == GM_DIRECT &&
                        !c->opt_graph && !(!c->par.rd_only && c->par.polarization) && !c->dirty_atoms.empty();
     if (!c->moves_deferred && !c->moves_in_pair && flush_moves(c)) return -1;
+    // (the pair kernel is launched whenever an atom moved; the long-range-correction kernels in front of it read
+    //  parameters only)
+    c->side_carry = c->moves_deferred && c->opt_side_moves && !c->dirty_atoms.empty() && c->pending.n <= kMaxMoves;
+    c->side_moves.n = 0;
     if (is_timed_call(c)) hipEventRecord(c->ev_first, c->stream);
 
     const DevAtoms a = dev_atoms(c);
@@ -1666,7 +1683,8 @@ static int enqueue_direct(mpmc_hip_ctx *c) {
         if (side_done) return;
         side_done = true;
         side_rc = [&]() -> int {
-        if (two_streams) hipStreamWaitEvent(sb, c->ev_fork, 0);  // after apply_moves: the new coordinates are in place
+        // after apply_moves: the new coordinates are in place (unless this stream's pair kernel brings the move itself)
+        if (two_streams && !(c->side_carry && c->side_moves.n > 0)) hipStreamWaitEvent(sb, c->ev_fork, 0);
         // ---- LJ long-range correction: parameters + volume only => cached (lj.c:56-107)
         if (P.rd_lrc) {
             // depends on parameters, the volume and WHICH atoms exist -- not on coordinates: summed once, its

@@ -824,27 +824,31 @@ def test_resident_solver_is_only_used_where_it_applies_and_falls_back_when_a_han
 
 
 def test_sweep_and_move_options_are_bit_neutral():
-    """sweep_alternate / sweep_nt / fuse_moves change how the step is executed, not one bit of what it computes."""
+    """sweep_alternate / sweep_nt / fuse_moves / side_moves change how the step is executed, not one bit of what it
+    computes (each energy term is compared: side_moves decides which stream's kernels learn of the move how)."""
     s = load("pcn61_bssp_4096") if os.path.exists(os.path.join(GOLD, "pcn61_bssp_4096.npz")) else synth.s_pol(2048)
     n = len(s["charge"])
     p = dict(temperature=77.0, polarization=1, polar_damp=2.1304, polar_max_iter=4, pbc_cutoff=8.0, feynman_hibbs=1,
              feynman_hibbs_order=4, polar_palmo=1)
     movable = np.where(~s["frozen"].astype(bool))[0]
     ref = None
-    for opts in ({}, {"sweep_alternate": 0}, {"sweep_nt": 1}, {"fuse_moves": 0}, {"sweep_alternate": 0, "fuse_moves": 0,
-                                                                                   "sweep_nt": 0}):
+    for opts in ({}, {"sweep_alternate": 0}, {"sweep_nt": 1}, {"fuse_moves": 0}, {"side_moves": 0},
+                 {"sweep_alternate": 0, "fuse_moves": 0, "sweep_nt": 0}):
         e = engine.Engine(n)
         e.load_system(s, p)
         for k, v in opts.items():
             e.set_option(k, v)
-        hist = [e.energy()["energy"]]
+        terms = ("energy", "rd_energy", "coulombic_energy", "polarization_energy")
+        r0 = e.energy()
+        hist = [tuple(r0[t] for t in terms)]
         rng = np.random.default_rng(11)
         for step in range(6):
             a = int(rng.choice(movable))
             idx = np.where(s["molecule"] == s["molecule"][a])[0]
             first, cnt = int(idx[0]), len(idx)
             e.update_atoms(first, s["pos"][first:first + cnt] + rng.normal(scale=0.1, size=3))
-            hist.append(e.energy()["energy"])
+            r = e.energy()
+            hist.append(tuple(r[t] for t in terms))
             if step % 2:
                 e.update_atoms(first, s["pos"][first:first + cnt])
         mu = e.dipoles()["mu"]
