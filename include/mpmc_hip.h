@@ -154,6 +154,9 @@ void mpmc_hip_destroy(mpmc_hip_ctx *ctx);
  *                          non-temporal only when the tile set exceeds the Infinity Cache (-1);
  *   "fuse_moves"          (default 1): a single-molecule move is applied inside the coefficient update of the step
  *                          (update_coef_moves_kernel) instead of by a launch of its own;
+ *   "split_record"        (default 1): in the Jacobi-type polarizable modes the LJ / Ewald stream publishes its own
+ *                          slots of the result record (sequence number of its own), so the main stream does not wait
+ *                          for it in front of its publish launch; 0 = join event + one record (A/B; same bits);
  *   "side_moves"          (default 1): in such a step the LJ / Ewald stream's pair kernel applies the same move for itself
  *                          (both streams write the same coordinates, neither reads a moved atom from memory), so no event
  *                          is recorded between the main stream's first two launches; 0 = fork event (A/B; same bits);

@@ -215,6 +215,8 @@ struct mpmc_hip_ctx {
     bool moves_deferred = false;           // pending moves not yet applied in the call being enqueued
     bool side_carry = false;               // ... and the side stream's pair kernel carries the same move itself (side_moves):
     MoveList side_moves;                   //     no fork event between the two streams in a steady-state polarizable step
+    int opt_split_record = 1;              // "split_record": the side stream publishes its own part of the result record
+    bool call_split = false;               // the call in flight did (energy_end waits for both sequence numbers)
     int opt_side_moves = 1;                // "side_moves": 0 = fork event after the main stream's move (A/B; same bits)
     unsigned long long resident_calls = 0, resident_fallbacks = 0;
     int opt_gs_ablate = 0;                 // timing-only ablations of the chain kernel (wrong results; tools/gs_ablate.py)
@@ -285,6 +287,8 @@ struct mpmc_hip_ctx {
     double *d_res = nullptr;  // R_COUNT doubles
     double *h_res = nullptr;  // pinned, mapped
     double *h_res_dev = nullptr;
+    double *h_res2 = nullptr;  // the side stream's part of the record (LJ / Ewald sums) with a sequence number of its own
+    double *h_res2_dev = nullptr;
     unsigned long long *h_err = nullptr;  // pinned, 1 word
     unsigned *h_gserr = nullptr;          // pinned: error words of the persistent Gauss-Seidel kernel (2 views)
     bool gs_used[2] = {false, false};
@@ -521,6 +525,8 @@ extern "C" int mpmc_hip_set_option(mpmc_hip_ctx *c, const char *name, int value)
         c->opt_res_fault = value;  // test hook: the next resident launch loses a hand-off (-> fallback)
     else if (!strcmp(name, "resident_stamps"))
         c->opt_res_stamps = value;
+    else if (!strcmp(name, "split_record"))
+        c->opt_split_record = value;  // 0: the main stream waits for the side stream (join event) and publishes everything
     else if (!strcmp(name, "side_moves"))
         c->opt_side_moves = value;  // 0: the side stream waits for an event recorded behind the main stream's move
     else if (!strcmp(name, "resident_fold"))
@@ -648,6 +654,9 @@ extern "C" int mpmc_hip_create(mpmc_hip_ctx **out, int device, int max_atoms) {
     HIPCHK(hipHostMalloc((void **)&c->h_res, (R_COUNT + 1) * sizeof(double), hipHostMallocMapped));
     c->h_res[R_COUNT] = 0.0;
     HIPCHK(hipHostGetDevicePointer((void **)&c->h_res_dev, c->h_res, 0));
+    HIPCHK(hipHostMalloc((void **)&c->h_res2, (R_COUNT + 1) * sizeof(double), hipHostMallocMapped));
+    memset(c->h_res2, 0, (R_COUNT + 1) * sizeof(double));
+    HIPCHK(hipHostGetDevicePointer((void **)&c->h_res2_dev, c->h_res2, 0));
     HIPCHK(hipHostMalloc((void **)&c->h_err, sizeof(unsigned long long), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&c->h_gserr, 2 * sizeof(unsigned), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&c->h_rank, np * sizeof(double), hipHostMallocDefault));
@@ -702,6 +711,7 @@ extern "C" void mpmc_hip_destroy(mpmc_hip_ctx *c) {
     if (c->ev_order) hipEventDestroy(c->ev_order);
     if (c->h_order) hipHostFree(c->h_order);
     if (c->h_res) hipHostFree(c->h_res);
+    if (c->h_res2) hipHostFree(c->h_res2);
     if (c->h_err) hipHostFree(c->h_err);
     if (c->h_gserr) hipHostFree(c->h_gserr);
     if (c->h_rank) hipHostFree(c->h_rank);
@@ -1475,7 +1485,8 @@ __global__ __launch_bounds__(mpmc::kReduceThreads) void publish_result_kernel(
     double *__restrict__ d_res, volatile double *__restrict__ h_res, int n, double seq,
     const double *__restrict__ energy_part, int nt, int n_total, const unsigned *__restrict__ gs_err0,
     const unsigned *__restrict__ gs_err1, const double *__restrict__ recip_chunk, int nrecip, unsigned zero_mask,
-    const double *__restrict__ pair_part, int pair_rows, int pair_slot) {
+    const double *__restrict__ pair_part, int pair_rows, int pair_slot, unsigned skip_mask) {
+    // (skip_mask: slots the side stream publishes itself -- publish_side_kernel -- and this kernel neither reads nor writes)
     // ---- the LJ / real-space Ewald tile partials (reduce_rows_kernel's arithmetic in reduce_rows_kernel's order: this
     // used to be a launch of its own behind the pair kernel): thread t takes rows t, t + 1024, ..., 64-lane butterflies,
     // then the 16 wave sums in order
@@ -1503,7 +1514,8 @@ __global__ __launch_bounds__(mpmc::kReduceThreads) void publish_result_kernel(
     }
     if (threadIdx.x >= 64) return;  // the record itself is one wave's work
     // terms this call does not compute (no long-range correction, Wolf instead of Ewald, no polarization) are zero
-    if ((int)threadIdx.x < n && ((zero_mask >> threadIdx.x) & 1u)) d_res[threadIdx.x] = 0.0;
+    const bool mine = (int)threadIdx.x < n && !((skip_mask >> threadIdx.x) & 1u);
+    if (mine && ((zero_mask >> threadIdx.x) & 1u)) d_res[threadIdx.x] = 0.0;
     double rec = 0.0, e = 0.0, r = 0.0;
     if (nrecip > 0) {  // reciprocal-space sum: chunk sums in chunk order
         for (int t = threadIdx.x; t < nrecip; t += 64) rec += recip_chunk[t];
@@ -1521,7 +1533,7 @@ __global__ __launch_bounds__(mpmc::kReduceThreads) void publish_result_kernel(
     // the record: what the other kernels left in d_res, with this kernel's sums in their slots (one wave: the values
     // travel in registers, a lane's own earlier store to its slot is ordered before its load)
     double v = 0.0;
-    if ((int)threadIdx.x < n) {
+    if (mine) {
         v = d_res[threadIdx.x];
         if ((zero_mask >> threadIdx.x) & 1u) v = 0.0;
         if (nrecip > 0 && threadIdx.x == R_RECIP) v = rec;
@@ -1535,6 +1547,31 @@ __global__ __launch_bounds__(mpmc::kReduceThreads) void publish_result_kernel(
     __threadfence_system();
     if (threadIdx.x == 0) h_res[n] = seq;
 }
+
+// The side stream's part of the record (the LJ / Ewald slots of side_mask), published by the side stream itself behind
+// its last kernel: the main stream then needs no join event in front of its own publish launch (a cross-stream wait
+// cost the S-POL(1024) step ~8 us), and mpmc_hip_energy_end() waits for both sequence numbers.  Same arithmetic as
+// publish_result_kernel for these slots (zeros for terms the call does not compute; chunk sums in chunk order).
+__global__ __launch_bounds__(64) void publish_side_kernel(double *__restrict__ d_res, volatile double *__restrict__ h_res2,
+                                                            int n, double seq, const double *__restrict__ recip_chunk,
+                                                            int nrecip, unsigned zero_mask, unsigned side_mask) {
+    double rec = 0.0;
+    if (nrecip > 0) {
+        for (int t = threadIdx.x; t < nrecip; t += 64) rec += recip_chunk[t];
+        rec = mpmc::wave_sum(rec);
+    }
+    if ((int)threadIdx.x < n && ((side_mask >> threadIdx.x) & 1u)) {
+        double v = d_res[threadIdx.x];
+        if ((zero_mask >> threadIdx.x) & 1u) v = 0.0;
+        if (nrecip > 0 && threadIdx.x == R_RECIP) v = rec;
+        d_res[threadIdx.x] = v;
+        h_res2[threadIdx.x] = v;
+    }
+    __threadfence_system();
+    if (threadIdx.x == 0) h_res2[n] = seq;
+}
+constexpr unsigned kSideSlots = (1u << R_RD_PAIR) | (1u << R_ES_REAL) | (1u << R_ES_INTRA) | (1u << 3) | (1u << R_LRC) |
+                                (1u << R_RECIP) | (1u << R_SELF);
 
 // LJ / real-space Ewald tile kernel (graph slot GS_PAIR).  Tile partials persist: after a single-molecule
 // move only the tiles of the moved atoms' blocks are recomputed.
@@ -1599,8 +1636,8 @@ static int launch_publish(mpmc_hip_ctx *c, bool do_polar) {
                        do_polar ? c->energy_nt : 0, c->n_valid,
                        c->gs_used[0] ? (const unsigned *)(c->view[0].gsflags + 1) : (const unsigned *)nullptr,
                        c->gs_used[1] ? (const unsigned *)(c->view[1].gsflags + 1) : (const unsigned *)nullptr,
-                       (const double *)c->d_recipsum, c->recip_chunks, c->res_zero_mask, (const double *)c->d_pairpart,
-                       c->pair_rows_to_sum, (int)R_RD_PAIR));
+                       (const double *)c->d_recipsum, c->call_split ? 0 : c->recip_chunks, c->res_zero_mask,
+                       (const double *)c->d_pairpart, c->pair_rows_to_sum, (int)R_RD_PAIR, c->call_split ? kSideSlots : 0u));
     return 0;
 }
 
@@ -1668,6 +1705,10 @@ static int enqueue_direct(mpmc_hip_ctx *c) {
     //  dependency costs several microseconds each way, a quarter of an LJ-only step)
     const bool two_streams = c->opt_overlap && !P.rd_only && P.polarization;
     hipStream_t sb = two_streams ? c->stream2 : c->stream;
+    // The side stream publishes its own slots of the record (no join event) in the Jacobi-type modes; the Gauss-Seidel
+    // modes keep the join (their ranking kernels share slots and streams with the chain), and so does graph capture.
+    c->call_split = two_streams && c->opt_split_record && !P.polar_gs && !P.polar_gs_ranked && c->graph_mode == GM_DIRECT &&
+                    !c->opt_graph;
     if (two_streams && !c->moves_deferred) hipEventRecord(c->ev_fork, c->stream);  // (the side stream's wait is issued when it is fed)
 
     const bool do_polar = !P.rd_only && P.polarization;
@@ -1767,7 +1808,12 @@ static int enqueue_direct(mpmc_hip_ctx *c) {
             c->res_zero_mask |= (1u << R_RECIP) | (1u << R_SELF);
             c->self_valid = false;
         }
-        if (two_streams) hipEventRecord(c->ev_join, sb);
+        if (c->call_split)
+            hipLaunchKernelGGL(publish_side_kernel, dim3(1), dim3(64), 0, sb, c->d_res, c->h_res2_dev, (int)R_COUNT,
+                               (double)c->energy_calls, (const double *)c->d_recipsum, c->recip_chunks, c->res_zero_mask,
+                               kSideSlots);
+        else if (two_streams)
+            hipEventRecord(c->ev_join, sb);
         return 0;
         }();
     };
@@ -1792,7 +1838,7 @@ static int enqueue_direct(mpmc_hip_ctx *c) {
     if (side_rc) return -1;
     if (c->pending.n > 0 && flush_moves(c)) return -1;  // (a move no launch of this call carried: cannot happen, but cheap)
     c->moves_in_pair = false;
-    if (two_streams) hipStreamWaitEvent(c->stream, c->ev_join, 0);
+    if (two_streams && !c->call_split) hipStreamWaitEvent(c->stream, c->ev_join, 0);
     const bool timed_call = is_timed_call(c);
     if (timed_call) hipEventRecord(c->ev_last, c->stream);
     if (launch_publish(c, do_polar)) return -1;
@@ -1872,6 +1918,7 @@ static int graph_step(mpmc_hip_ctx *c) {
     timespec g0, g1, g2;
     clock_gettime(CLOCK_MONOTONIC, &g0);
     c->graph_mode = GM_UPDATE;
+    c->call_split = false;  // (a captured step joins its two streams and publishes one record)
     int rc = flush_moves(c);
     if (!rc) rc = setup_view(c, c->view[0], a, bx, true, true, false);
     if (!rc) rc = launch_field(c, a, bx);
@@ -2002,6 +2049,19 @@ extern "C" int mpmc_hip_energy_end(mpmc_hip_ctx *c, mpmc_hip_result *out) {
             __builtin_ia32_pause();
         }
         if (!seen) HIPCHK(hipStreamSynchronize(c->stream));
+        if (c->call_split) {  // the side stream's part has a sequence number of its own
+            volatile double *seq2 = c->h_res2 + R_COUNT;
+            seen = false;
+            for (unsigned long long spins = 0; spins < 2000000000ull; ++spins) {
+                if (*seq2 == want) {
+                    seen = true;
+                    break;
+                }
+                if ((spins & 0xfffffull) == 0xfffffull && hipStreamQuery(c->stream2) != hipErrorNotReady) break;
+                __builtin_ia32_pause();
+            }
+            if (!seen) HIPCHK(hipStreamSynchronize(c->stream2));
+        }
         return 0;
     };
     if (wait_record()) return -1;
@@ -2062,7 +2122,8 @@ extern "C" int mpmc_hip_energy_end(mpmc_hip_ctx *c, mpmc_hip_result *out) {
     c->timed = timed_call;
     c->stage_used = 0;
 
-    const double *r = c->h_res;
+    double r[R_COUNT];
+    for (int k = 0; k < R_COUNT; ++k) r[k] = (c->call_split && ((kSideSlots >> k) & 1u)) ? c->h_res2[k] : c->h_res[k];
     const double rd = r[R_RD_PAIR] + r[R_LRC];
     const double real = r[R_ES_REAL] - r[R_ES_INTRA];
     const bool ewald = !P.rd_only && !P.wolf;
