@@ -62,6 +62,8 @@ struct MoveTargets {  // where a kernel that carries the move writes it (what ap
     double *px, *py, *pz;
 };
 
+
+
 struct DevAtoms {
     const double *x, *y, *z;
     const double *q, *alpha, *eps, *sig, *molmass;
@@ -69,6 +71,21 @@ struct DevAtoms {
     const int *flags;
     int n, npad;
 };
+
+// position of atom i: from the step's move when it carries one for i, else from memory
+__device__ __forceinline__ void moved_position(const DevAtoms &a, const MoveList &m, int i, double &x, double &y,
+                                               double &z) {
+    x = a.x[i];
+    y = a.y[i];
+    z = a.z[i];
+    for (int e = 0; e < m.n; ++e) {
+        if (m.idx[e] == i) {
+            x = m.x[e];
+            y = m.y[e];
+            z = m.z[e];
+        }
+    }
+}
 
 // Minimum image exactly as the reference evaluates it (src/energy/pairs.c:230-290):
 // same operation order, no FMA contraction, so the lattice translation picked by

@@ -217,6 +217,10 @@ struct mpmc_hip_ctx {
     MoveList side_moves;                   //     no fork event between the two streams in a steady-state polarizable step
     int opt_split_record = 1;              // "split_record": the side stream publishes its own part of the result record
     bool call_split = false;               // the call in flight did (energy_end waits for both sequence numbers)
+    int opt_fuse_field = 1;                // "fuse_field": the move + coefficient update ride inside the field kernel's launch
+    bool coef_job_valid = false;           // setup_view() left the coefficient update of this step for launch_field()
+    bool coef_job_fork = false;            //   ... which then also records the fork event behind it
+    CoefJob coef_job;
     int opt_side_moves = 1;                // "side_moves": 0 = fork event after the main stream's move (A/B; same bits)
     unsigned long long resident_calls = 0, resident_fallbacks = 0;
     int opt_gs_ablate = 0;                 // timing-only ablations of the chain kernel (wrong results; tools/gs_ablate.py)
@@ -527,6 +531,8 @@ extern "C" int mpmc_hip_set_option(mpmc_hip_ctx *c, const char *name, int value)
         c->opt_res_stamps = value;
     else if (!strcmp(name, "split_record"))
         c->opt_split_record = value;  // 0: the main stream waits for the side stream (join event) and publishes everything
+    else if (!strcmp(name, "fuse_field"))
+        c->opt_fuse_field = value;  // 0: update_coef_moves_kernel as a launch of its own in front of the field kernel
     else if (!strcmp(name, "side_moves"))
         c->opt_side_moves = value;  // 0: the side stream waits for an event recorded behind the main stream's move
     else if (!strcmp(name, "resident_fold"))

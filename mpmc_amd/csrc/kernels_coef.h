@@ -162,14 +162,16 @@ struct DirtyMoves {
     int slot[kMaxDirtyMoves];
     double x[kMaxDirtyMoves], y[kMaxDirtyMoves], z[kMaxDirtyMoves];
 };
-__global__ __launch_bounds__(64) void update_coef_moves_kernel(DevAtoms a, DevBox bx, double damp, DirtyMoves dm, int ntld,
-                                                                double2 *__restrict__ C, MoveList m,
-                                                                double *__restrict__ gx, double *__restrict__ gy,
-                                                                double *__restrict__ gz,
-                                                                const int *__restrict__ slot_of_atom, double *px, double *py,
-                                                                double *pz) {
-    if (blockIdx.x == 0 && blockIdx.y == 0 && (int)threadIdx.x < m.n) {  // apply_moves_kernel's stores
-        const int e = threadIdx.x, at = m.idx[e];
+// (bxi, byi: what blockIdx.x / blockIdx.y are in update_coef_moves_kernel's own grid (nt, dm.n); t64: the thread within
+//  its 64; writer: the one unit that stores the moved coordinates)
+__device__ __forceinline__ void update_coef_moves_body(int bxi, int byi, int t64, bool writer, const DevAtoms &a,
+                                                       const DevBox &bx, double damp, const DirtyMoves &dm, int ntld,
+                                                       double2 *__restrict__ C, const MoveList &m, double *__restrict__ gx,
+                                                       double *__restrict__ gy, double *__restrict__ gz,
+                                                       const int *__restrict__ slot_of_atom, double *px, double *py,
+                                                       double *pz) {
+    if (writer && t64 < m.n) {  // apply_moves_kernel's stores
+        const int e = t64, at = m.idx[e];
         gx[at] = m.x[e];
         gy[at] = m.y[e];
         gz[at] = m.z[e];
@@ -180,10 +182,10 @@ __global__ __launch_bounds__(64) void update_coef_moves_kernel(DevAtoms a, DevBo
             pz[s] = m.z[e];
         }
     }
-    const int sa = dm.slot[blockIdx.y];
-    const int k = blockIdx.x * 64 + threadIdx.x;
+    const int sa = dm.slot[byi];
+    const int k = bxi * 64 + t64;
     if (k == sa) return;
-    double xa = dm.x[blockIdx.y], ya = dm.y[blockIdx.y], za = dm.z[blockIdx.y];
+    double xa = dm.x[byi], ya = dm.y[byi], za = dm.z[byi];
     double xk = a.x[k], yk = a.y[k], zk = a.z[k];
     for (int q = 0; q < dm.n; ++q) {  // a partner that moved too (same molecule): its new position
         if (dm.slot[q] == k) {
@@ -211,6 +213,48 @@ __global__ __launch_bounds__(64) void update_coef_moves_kernel(DevAtoms a, DevBo
         tile[((lk - la) & 63) * 64 + la] = v;
         tile[((la - lk) & 63) * 64 + lk] = v;
     }
+}
+
+__global__ __launch_bounds__(64) void update_coef_moves_kernel(DevAtoms a, DevBox bx, double damp, DirtyMoves dm, int ntld,
+                                                                double2 *__restrict__ C, MoveList m,
+                                                                double *__restrict__ gx, double *__restrict__ gy,
+                                                                double *__restrict__ gz,
+                                                                const int *__restrict__ slot_of_atom, double *px, double *py,
+                                                                double *pz) {
+    update_coef_moves_body(blockIdx.x, blockIdx.y, threadIdx.x, blockIdx.x == 0 && blockIdx.y == 0, a, bx, damp, dm, ntld, C,
+                           m, gx, gy, gz, slot_of_atom, px, py, pz);
+}
+
+// The move, the coefficient update AND the incremental static-field pass of a steady-state step as ONE launch: the two
+// are independent (each needs only the moved atoms' new coordinates, which travel in the kernel arguments), so the
+// coefficient update's units ride in a third z-slice of the field kernel's incremental grid (8 of them per 512-thread
+// workgroup, one per wave) instead of being a launch of their own in front of it -- one launch and ~4.5 us of kernel
+// less on the step's dependent chain.  No thread of either role reads a moved atom's position from memory
+// (static_field_body takes it from the MoveList), unit 0 of the coefficient role stores the coordinates.  Same
+// functions of the same coordinates => same bits as the two launches.
+struct CoefJob {
+    DevAtoms pa;   // the view's atoms (update_coef_moves_kernel's `a`)
+    double damp;
+    DirtyMoves dm;
+    int nt, ntld;
+    double2 *C;
+    MoveList m;
+    double *gx, *gy, *gz;
+    const int *slot_of_atom;
+    double *px, *py, *pz;
+};
+template <int MODE>
+__global__ __launch_bounds__(64 * kFieldWaves) void field_coef_kernel(DevAtoms a, DevBox bx, FieldParams fp, DirtyBlocks sel,
+                                                                       double *__restrict__ part, CoefJob cj) {
+    if (blockIdx.z == 2) {
+        const int u = ((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x) * kFieldWaves + ((int)threadIdx.x >> 6);
+        const int bxi = u % cj.nt, byi = u / cj.nt;
+        if (byi < cj.dm.n)
+            update_coef_moves_body(bxi, byi, threadIdx.x & 63, u == 0, cj.pa, bx, cj.damp, cj.dm, cj.ntld, cj.C, cj.m, cj.gx,
+                                   cj.gy, cj.gz, cj.slot_of_atom, cj.px, cj.py, cj.pz);
+        return;
+    }
+    static_field_body<MODE>(a, bx, fp, sel, part, cj.m);
 }
 
 // ---------------------------------------------------------------------------------------------

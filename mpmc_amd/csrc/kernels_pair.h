@@ -33,21 +33,6 @@ struct JTile {
     int mol[kWave], flags[kWave];
 };
 
-// position of atom i: from the step's move when it carries one for i, else from memory
-__device__ __forceinline__ void moved_position(const DevAtoms &a, const MoveList &m, int i, double &x, double &y,
-                                               double &z) {
-    x = a.x[i];
-    y = a.y[i];
-    z = a.z[i];
-    for (int e = 0; e < m.n; ++e) {
-        if (m.idx[e] == i) {
-            x = m.x[e];
-            y = m.y[e];
-            z = m.z[e];
-        }
-    }
-}
-
 __device__ __forceinline__ void load_jtile(JTile &t, const DevAtoms &a, const MoveList &m, int j0, int lane) {
     int j = j0 + lane;  // j < npad always (grid covers npad/64 tiles)
     moved_position(a, m, j, t.x[lane], t.y[lane], t.z[lane]);

@@ -37,10 +37,11 @@ struct FieldParams {
 // 64/kFieldWaves of each staged group of partners; the waves' sums are combined in a fixed order.
 constexpr int kFieldWaves = 8;
 constexpr int kFieldJPerWave = kWave / kFieldWaves;
+// (m: the step's move when the launch that runs this body also APPLIES it -- field_coef_kernel, kernels_coef.h: a moved
+//  atom's position is then taken from the list, never from memory; m.n = 0 otherwise)
 template <int MODE>
-__global__ __launch_bounds__(64 * kFieldWaves) void static_field_kernel(DevAtoms a, DevBox bx, FieldParams fp,
-                                                                         DirtyBlocks sel,
-                                                                         double *__restrict__ part) {
+__device__ __forceinline__ void static_field_body(const DevAtoms &a, const DevBox &bx, const FieldParams &fp,
+                                                  const DirtyBlocks &sel, double *__restrict__ part, const MoveList &m) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int tile = blockIdx.y, chunk = blockIdx.x;
     if (sel.n > 0) {
@@ -61,7 +62,8 @@ __global__ __launch_bounds__(64 * kFieldWaves) void static_field_kernel(DevAtoms
     __shared__ int smol[kWave], sfl[kWave];
     __shared__ double red[kFieldWaves][3][kWave];
 
-    const double xi = a.x[i], yi = a.y[i], zi = a.z[i];
+    double xi, yi, zi;
+    moved_position(a, m, i, xi, yi, zi);
     const float xif = (float)xi, yif = (float)yi, zif = (float)zi;
     const double qi = a.q[i];
     const int moli = a.mol[i], fli = a.flags[i];
@@ -73,9 +75,7 @@ __global__ __launch_bounds__(64 * kFieldWaves) void static_field_kernel(DevAtoms
     for (int j0 = jbeg; j0 < jbeg + fp.chunk && j0 < a.npad; j0 += kWave) {
         __syncthreads();
         if (wv == 0) {
-            sx[lane] = a.x[j0 + lane];
-            sy[lane] = a.y[j0 + lane];
-            sz[lane] = a.z[j0 + lane];
+            moved_position(a, m, j0 + lane, sx[lane], sy[lane], sz[lane]);
             fx[lane] = (float)sx[lane];
             fy[lane] = (float)sy[lane];
             fz[lane] = (float)sz[lane];
@@ -150,6 +150,15 @@ __global__ __launch_bounds__(64 * kFieldWaves) void static_field_kernel(DevAtoms
         for (int k = 0; k < kFieldWaves; ++k) s += red[k][wv][lane];
         part[(size_t)chunk * 3 * a.npad + (size_t)wv * a.npad + i] = s;
     }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64 * kFieldWaves) void static_field_kernel(DevAtoms a, DevBox bx, FieldParams fp,
+                                                                         DirtyBlocks sel,
+                                                                         double *__restrict__ part) {
+    MoveList m;
+    m.n = 0;
+    static_field_body<MODE>(a, bx, fp, sel, part, m);
 }
 
 // Reciprocal part of the Ewald static field (recip_term(), polar_ewald.c:85-132):

@@ -824,7 +824,7 @@ def test_resident_solver_is_only_used_where_it_applies_and_falls_back_when_a_han
 
 
 def test_sweep_and_move_options_are_bit_neutral():
-    """sweep_alternate / sweep_nt / fuse_moves / side_moves / split_record change how the step is executed, not one bit of what it
+    """sweep_alternate / sweep_nt / fuse_moves / fuse_field / side_moves / split_record change how the step is executed, not one bit of what it
     computes (each energy term is compared: side_moves decides which stream's kernels learn of the move how)."""
     s = load("pcn61_bssp_4096") if os.path.exists(os.path.join(GOLD, "pcn61_bssp_4096.npz")) else synth.s_pol(2048)
     n = len(s["charge"])
@@ -832,7 +832,7 @@ def test_sweep_and_move_options_are_bit_neutral():
              feynman_hibbs_order=4, polar_palmo=1)
     movable = np.where(~s["frozen"].astype(bool))[0]
     ref = None
-    for opts in ({}, {"sweep_alternate": 0}, {"sweep_nt": 1}, {"fuse_moves": 0}, {"side_moves": 0}, {"split_record": 0},
+    for opts in ({}, {"sweep_alternate": 0}, {"sweep_nt": 1}, {"fuse_moves": 0}, {"fuse_field": 0}, {"side_moves": 0}, {"split_record": 0},
                  {"sweep_alternate": 0, "fuse_moves": 0, "sweep_nt": 0}):
         e = engine.Engine(n)
         e.load_system(s, p)
