@@ -488,6 +488,18 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
 #pragma unroll
         for (int f2 = 0; f2 < 18; ++f2) asm volatile("" : "+v"(mm[f2].x), "+v"(mm[f2].y));  // (keeps them in registers)
     }
+    // per-lane role of this wave's four column groups (static): the column whose vector the lane multiplies and the
+    // 0 / 1 weights of the two accumulators (row lane | row 63 - lane); set up here, ahead of the hand-off
+    int mv_col[4];
+    double mv_w1[4], mv_w2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int g = w + 8 * k;
+        const bool r1 = lane > g;
+        mv_col[k] = r1 ? g : ((g <= 30) ? 62 - g : g);
+        mv_w1[k] = r1 ? 1.0 : 0.0;
+        mv_w2[k] = r1 ? 0.0 : 1.0;
+    }
     {
     GS_STAMP(6);
     if (t >= 1) {
@@ -533,27 +545,28 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
     }
     __syncthreads();
     GS_STAMP(9);
-    // M_t v_t: wave w takes the column groups g = w, w + 8, w + 16, w + 24 of the folded inverse
+    // M_t v_t: wave w takes the column groups g = w, w + 8, w + 16, w + 24 of the folded inverse.  A lane holds ONE 3 x 3
+    // entry per group: of (row lane, column g) if lane > g [role 1], else of (row 63 - lane, column 62 - g) [role 2].  The
+    // vector it multiplies is fetched with a per-lane LDS address (two distinct addresses per wave instruction), the
+    // product t = E b is formed once (9 operations) and added to the role's accumulator through a 0 / 1 weight: 15 fp64
+    // operations per group instead of 18 FMAs + 12 v_cndmask_b32 -- this stage is VALU-bound (two waves per SIMD, every
+    // instruction four cycles: 0.8 us of a block's 2.4 before, in-kernel stamps).
     {
         double a1x = 0.0, a1y = 0.0, a1z = 0.0, a2x = 0.0, a2y = 0.0, a2z = 0.0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int g = w + 8 * k;
-            const bool r1 = lane > g;  // role 1: (row lane, column g); role 2: (row 63 - lane, column 62 - g)
-            const int c1 = g, c2 = (g <= 30) ? 62 - g : g;
-            // the inactive role's vector is zeroed instead of selecting results
-            const double b1x = smu[c1], b1y = smu[64 + c1], b1z = smu[128 + c1];
-            const double b2x = smu[c2], b2y = smu[64 + c2], b2z = smu[128 + c2];
-            const double x1 = r1 ? b1x : 0.0, y1 = r1 ? b1y : 0.0, z1 = r1 ? b1z : 0.0;
-            const double x2 = r1 ? 0.0 : b2x, y2 = r1 ? 0.0 : b2y, z2 = r1 ? 0.0 : b2z;
+            const double bx_ = smu[mv_col[k]], by_ = smu[64 + mv_col[k]], bz_ = smu[128 + mv_col[k]];
 #define MINV_E(e) (((9 * k + (e)) & 1) ? mm[(9 * k + (e)) >> 1].y : mm[(9 * k + (e)) >> 1].x)
-            a1x = fma(MINV_E(2), z1, fma(MINV_E(1), y1, fma(MINV_E(0), x1, a1x)));
-            a1y = fma(MINV_E(5), z1, fma(MINV_E(4), y1, fma(MINV_E(3), x1, a1y)));
-            a1z = fma(MINV_E(8), z1, fma(MINV_E(7), y1, fma(MINV_E(6), x1, a1z)));
-            a2x = fma(MINV_E(2), z2, fma(MINV_E(1), y2, fma(MINV_E(0), x2, a2x)));
-            a2y = fma(MINV_E(5), z2, fma(MINV_E(4), y2, fma(MINV_E(3), x2, a2y)));
-            a2z = fma(MINV_E(8), z2, fma(MINV_E(7), y2, fma(MINV_E(6), x2, a2z)));
+            const double tx = fma(MINV_E(2), bz_, fma(MINV_E(1), by_, MINV_E(0) * bx_));
+            const double ty = fma(MINV_E(5), bz_, fma(MINV_E(4), by_, MINV_E(3) * bx_));
+            const double tz = fma(MINV_E(8), bz_, fma(MINV_E(7), by_, MINV_E(6) * bx_));
 #undef MINV_E
+            a1x = fma(mv_w1[k], tx, a1x);
+            a1y = fma(mv_w1[k], ty, a1y);
+            a1z = fma(mv_w1[k], tz, a1z);
+            a2x = fma(mv_w2[k], tx, a2x);
+            a2y = fma(mv_w2[k], ty, a2y);
+            a2z = fma(mv_w2[k], tz, a2z);
         }
         // role-2 sums belong to row 63 - lane: mirror them across the wave
         a1x += __shfl(a2x, 63 - lane, 64);
