@@ -217,6 +217,7 @@ struct mpmc_hip_ctx {
     MoveList side_moves;                   //     no fork event between the two streams in a steady-state polarizable step
     int opt_split_record = 1;              // "split_record": the side stream publishes its own part of the result record
     bool call_split = false;               // the call in flight did (energy_end waits for both sequence numbers)
+    int opt_rank_late = 1;                 // "rank_late": polar_gs_ranked's side-stream ranking work is enqueued behind the first sweep
     int opt_fuse_field = 1;                // "fuse_field": the move + coefficient update ride inside the field kernel's launch
     bool coef_job_valid = false;           // setup_view() left the coefficient update of this step for launch_field()
     bool coef_job_fork = false;            //   ... which then also records the fork event behind it
@@ -531,6 +532,8 @@ extern "C" int mpmc_hip_set_option(mpmc_hip_ctx *c, const char *name, int value)
         c->opt_res_stamps = value;
     else if (!strcmp(name, "split_record"))
         c->opt_split_record = value;  // 0: the main stream waits for the side stream (join event) and publishes everything
+    else if (!strcmp(name, "rank_late"))
+        c->opt_rank_late = value;  // 0: in front of the main stream's view set-up (A/B; same results)
     else if (!strcmp(name, "fuse_field"))
         c->opt_fuse_field = value;  // 0: update_coef_moves_kernel as a launch of its own in front of the field kernel
     else if (!strcmp(name, "side_moves"))
