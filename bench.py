@@ -32,8 +32,10 @@ same chain with --full-rebuild semantics; (5) the CPU baseline (rank 0, N = 1 on
 A/B switches (none changes what is computed; see include/mpmc_hip.h for the engine options behind them):
   --expanded-matrix / --full-sweep / --full-rebuild, --uvt, --walkers-per-gpu W, and the environment variables
   MPMC_OVERLAP=0|1 (second stream), MPMC_SIDE_AFTER=n (where the side stream is fed), MPMC_STEP_GRAPH=1 (HIP-graph
-  replay), MPMC_SYM_MODE, MPMC_GS_DEBUG, MPMC_WALKERS_ONE_THREAD=1, MPMC_HIP_HOST_PROFILE=1 (host-side timing of
-  energy(): printed to stderr when the contexts are destroyed).
+  replay), MPMC_SYM_MODE, MPMC_GS_DEBUG, MPMC_RESIDENT / MPMC_RESIDENT_FOLD (one-launch dipole solve, with / without
+  finisher workgroups), MPMC_SIDE_MOVES / MPMC_SPLIT_RECORD / MPMC_FUSE_FIELD / MPMC_RANK_LATE (=0: fork event, join event,
+  coefficient update as its own launch, ranking work enqueued first), MPMC_WALKERS_ONE_THREAD=1, MPMC_HIP_HOST_PROFILE=1
+  (host-side timing of energy(): printed to stderr when the contexts are destroyed).
 """
 import argparse
 import glob
@@ -413,7 +415,7 @@ def main():
     elapsed = float(tmax.item())
 
     # ---- untimed pass 1: the dominant kernel under HIP events on the engine's stream, every launch, raw mean
-    nprobe = 48
+    nprobe = 96
     chain.set_option("timing", 1)
     chain.set_option("timing_interval", 1)
     chain.enable_timing(True)
@@ -464,12 +466,15 @@ def main():
                 + nblk * 18432 * 8 + 6 * m3 * 8
             kernel_name = "gs_chain_kernel"
         elif not expanded and acc.get("resident_calls", 0) > 0 and acc["sweep_count"] <= nprobe + 1:
-            # small views: the whole solve is ONE launch (jacobi_resident_kernel) whose tiles stay in registers; priced
+            # small views: the whole solve is ONE launch (jacobi_folded_kernel up to 16 blocks, jacobi_resident_kernel up
+            # to 21) whose tiles stay in registers; priced
             # at the bytes the sweeps of the solve need algorithmically (n_iter passes over the coefficients), so this
             # is an EFFECTIVE bandwidth -- the launch itself reads the coefficients from memory once
             n_iter = int(flags.get("polar_max_iter", 10))
             sweep_bytes = n_iter * (n_pol * (n_pol - 1) / 2 * 16 + 3 * m3 * 8)
-            kernel_name = "jacobi_resident_kernel (%d sweeps in one launch, tiles held in registers: effective bandwidth)" % n_iter
+            kernel_name = ("%s (%d sweeps in one launch, tiles held in registers: effective bandwidth)"
+                           % ("jacobi_folded_kernel" if nblk <= 16 and not os.environ.get("MPMC_RESIDENT_FOLD")
+                              else "jacobi_resident_kernel / jacobi_folded_kernel", n_iter))
         elif not expanded:
             sweep_bytes = n_pol * (n_pol - 1) / 2 * 16 + 3 * m3 * 8
             kernel_name = "pair_sweep_kernel"
