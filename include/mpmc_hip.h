@@ -160,6 +160,9 @@ void mpmc_hip_destroy(mpmc_hip_ctx *ctx);
  *   "fuse_field"          (default 1): ... and both ride in a third z-slice of the incremental static-field launch
  *                          (field_coef_kernel): the step's first launch does the move, the coefficient update and the
  *                          field; 0 = update_coef_moves_kernel as a launch of its own (A/B; same bits);
+ *   "fuse_recip"          (default 1): the reciprocal-space partial structure factors ride in a second z-slice of the
+ *                          pair kernel's launch (pair_recip_kernel) when both passes cover the same blocks; 0 =
+ *                          recip_partial_kernel as a launch of its own (A/B; same bits);
  *   "split_record"        (default 1): in the Jacobi-type polarizable modes the LJ / Ewald stream publishes its own
  *                          slots of the result record (sequence number of its own), so the main stream does not wait
  *                          for it in front of its publish launch; 0 = join event + one record (A/B; same bits);

@@ -217,6 +217,8 @@ struct mpmc_hip_ctx {
     MoveList side_moves;                   //     no fork event between the two streams in a steady-state polarizable step
     int opt_split_record = 1;              // "split_record": the side stream publishes its own part of the result record
     bool call_split = false;               // the call in flight did (energy_end waits for both sequence numbers)
+    int opt_fuse_recip = 1;                // "fuse_recip": the reciprocal-space partials ride in the pair kernel's launch
+    bool recip_fused = false;              // ... and did, in the call being enqueued
     int opt_rank_late = 1;                 // "rank_late": polar_gs_ranked's side-stream ranking work is enqueued behind the first sweep
     int opt_fuse_field = 1;                // "fuse_field": the move + coefficient update ride inside the field kernel's launch
     bool coef_job_valid = false;           // setup_view() left the coefficient update of this step for launch_field()
@@ -532,6 +534,8 @@ extern "C" int mpmc_hip_set_option(mpmc_hip_ctx *c, const char *name, int value)
         c->opt_res_stamps = value;
     else if (!strcmp(name, "split_record"))
         c->opt_split_record = value;  // 0: the main stream waits for the side stream (join event) and publishes everything
+    else if (!strcmp(name, "fuse_recip"))
+        c->opt_fuse_recip = value;  // 0: recip_partial_kernel as a launch of its own behind the pair kernel
     else if (!strcmp(name, "rank_late"))
         c->opt_rank_late = value;  // 0: in front of the main stream's view set-up (A/B; same results)
     else if (!strcmp(name, "fuse_field"))
@@ -1584,7 +1588,8 @@ constexpr unsigned kSideSlots = (1u << R_RD_PAIR) | (1u << R_ES_REAL) | (1u << R
 
 // LJ / real-space Ewald tile kernel (graph slot GS_PAIR).  Tile partials persist: after a single-molecule
 // move only the tiles of the moved atoms' blocks are recomputed.
-static int launch_pair_kernel(mpmc_hip_ctx *c, const DevAtoms &a, const DevBox &bx, hipStream_t sb) {
+static int launch_pair_kernel(mpmc_hip_ctx *c, const DevAtoms &a, const DevBox &bx, hipStream_t sb,
+                              bool with_recip = false) {
     const mpmc_hip_params &P = c->par;
     const int ntile = c->npad / 64;
     PairParams pp;
@@ -1597,6 +1602,7 @@ static int launch_pair_kernel(mpmc_hip_ctx *c, const DevAtoms &a, const DevBox &
     DirtyBlocks sel = c->dirty_blocks;
     if (!c->pair_part_valid) sel.n = 0;
     const dim3 grid(ntile, sel.n > 0 ? sel.n : ntile), block(64 * kPairWaves);
+    c->recip_fused = false;
     if (c->pair_part_valid && c->dirty_atoms.empty()) return 0;  // nothing moved since the partials were made
     // the step's move, when this launch carries it (steps without polarization: enqueue_direct)
     MoveList mv;
@@ -1615,6 +1621,29 @@ static int launch_pair_kernel(mpmc_hip_ctx *c, const DevAtoms &a, const DevBox &
     }
     c->side_moves.n = 0;
     c->moves_in_pair = false;
+    if (with_recip && c->opt_fuse_recip && c->graph_mode == GM_DIRECT && !c->opt_graph && c->nk > 0 &&
+        (c->nk + 63) / 64 <= ntile) {
+        // the reciprocal-space partials of the same blocks ride in a second z-slice of this launch (pair_recip_kernel) when
+        // both passes are of the same kind: incremental over the same dirty blocks, or full
+        DirtyBlocks rsel = c->dirty_blocks;
+        if (!c->recip_part_valid || !c->pair_part_valid_before) rsel.n = 0;
+        const bool recip_skipped = c->recip_part_valid && c->pair_part_valid_before && c->dirty_atoms.empty();
+        if (!recip_skipped && rsel.n == sel.n) {
+            const dim3 g2(grid.x, grid.y, 2);
+            RecipJob rj = {(const KVec *)c->d_kvec, c->nk, c->d_sfpart};
+            if (pp.fh_order == 0)
+                hipLaunchKernelGGL(pair_recip_kernel<0>, g2, block, 0, sb, a, bx, pp, sel, c->d_pairpart, mv, mt, rj);
+            else if (pp.fh_order == 2)
+                hipLaunchKernelGGL(pair_recip_kernel<2>, g2, block, 0, sb, a, bx, pp, sel, c->d_pairpart, mv, mt, rj);
+            else
+                hipLaunchKernelGGL(pair_recip_kernel<4>, g2, block, 0, sb, a, bx, pp, sel, c->d_pairpart, mv, mt, rj);
+            HIPCHK(hipGetLastError());
+            c->pair_part_valid = true;
+            c->recip_part_valid = true;
+            c->recip_fused = true;
+            return 0;
+        }
+    }
     if (pp.fh_order == 0)
         HIPCHK(launch_slot(c, GS_PAIR, pair_rd_es_kernel<0>, grid, block, sb, a, bx, pp, sel, c->d_pairpart, mv, mt));
     else if (pp.fh_order == 2)
@@ -1770,9 +1799,25 @@ static int enqueue_direct(mpmc_hip_ctx *c) {
         }
 
         // ---- fused pair kernel: LJ(+FH) and real-space Ewald(+FH, + intra-molecular screening)
+        const bool ewald_recip = !P.rd_only && !P.wolf && c->nk > 0;
+        if (ewald_recip) {
+            // partial structure factors per 64-atom block stay resident; only the moved blocks are redone
+            const size_t need = (size_t)(c->max_npad / 64) * c->nk;
+            if (c->sfpart_cap < need) {
+                if (c->d_sfpart) hipFree(c->d_sfpart);
+                c->d_sfpart = nullptr;
+                c->sfpart_cap = 0;
+                HIPCHK(hipMalloc((void **)&c->d_sfpart, need * sizeof(double2)));
+                if (c->d_recipsum) hipFree(c->d_recipsum);
+                c->d_recipsum = nullptr;
+                HIPCHK(hipMalloc((void **)&c->d_recipsum, ((c->nk + 63) / 64) * sizeof(double)));
+                c->sfpart_cap = need;
+                c->recip_part_valid = false;
+            }
+        }
         {
             ScopedTimer t(c, T_PAIR, sb);
-            if (launch_pair_kernel(c, a, bx, sb)) return -1;
+            if (launch_pair_kernel(c, a, bx, sb, ewald_recip)) return -1;
             if (two_streams) {
                 // beside the polarization chain the sum is free on the side stream, and would be 3.5 us of the main one
                 hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(kReduceThreads), 0, sb, c->d_pairpart, ntile * ntile,
@@ -1787,20 +1832,7 @@ static int enqueue_direct(mpmc_hip_ctx *c) {
         if (!P.rd_only && !P.wolf) {
             ScopedTimer t(c, T_RECIP, sb);
             if (c->nk > 0) {
-                // partial structure factors per 64-atom block stay resident; only the moved blocks are redone
-                const size_t need = (size_t)(c->max_npad / 64) * c->nk;
-                if (c->sfpart_cap < need) {
-                    if (c->d_sfpart) hipFree(c->d_sfpart);
-                    c->d_sfpart = nullptr;
-                    c->sfpart_cap = 0;
-                    HIPCHK(hipMalloc((void **)&c->d_sfpart, need * sizeof(double2)));
-                    if (c->d_recipsum) hipFree(c->d_recipsum);
-                    c->d_recipsum = nullptr;
-                    HIPCHK(hipMalloc((void **)&c->d_recipsum, ((c->nk + 63) / 64) * sizeof(double)));
-                    c->sfpart_cap = need;
-                    c->recip_part_valid = false;
-                }
-                if (launch_recip_partial(c, a, sb)) return -1;
+                if (!c->recip_fused && launch_recip_partial(c, a, sb)) return -1;
                 hipLaunchKernelGGL(recip_sum_kernel, dim3((c->nk + 63) / 64), dim3(64 * kRecipGroups), 0, sb, c->d_kvec,
                                    c->nk, ntile, c->d_sfpart, c->d_recipsum);
                 c->recip_chunks = (c->nk + 63) / 64;

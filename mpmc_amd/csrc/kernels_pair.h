@@ -58,10 +58,9 @@ __device__ __forceinline__ void load_jtile(JTile &t, const DevAtoms &a, const Mo
 constexpr int kPairWaves = 8;
 constexpr int kPairJPerWave = kWave / kPairWaves;
 template <int FH>
-__global__ __launch_bounds__(64 * kPairWaves) void pair_rd_es_kernel(DevAtoms a, DevBox bx, PairParams pp,
-                                                                      DirtyBlocks sel,
-                                                                      double *__restrict__ partials, MoveList m,
-                                                                      MoveTargets mt) {
+__device__ __forceinline__ void pair_rd_es_body(const DevAtoms &a, const DevBox &bx, const PairParams &pp,
+                                                const DirtyBlocks &sel, double *__restrict__ partials, const MoveList &m,
+                                                const MoveTargets &mt) {
     // In a step without polarization the MC move rides in THIS launch (m.n > 0; with polarization it rides in the
     // coefficient update): every thread takes a moved atom's position from the list, never from memory, and workgroup
     // (0, 0) writes the coordinate arrays for the kernels behind this one.
@@ -228,6 +227,14 @@ __global__ __launch_bounds__(64 * kPairWaves) void pair_rd_es_kernel(DevAtoms a,
     }
 }
 
+template <int FH>
+__global__ __launch_bounds__(64 * kPairWaves) void pair_rd_es_kernel(DevAtoms a, DevBox bx, PairParams pp,
+                                                                      DirtyBlocks sel,
+                                                                      double *__restrict__ partials, MoveList m,
+                                                                      MoveTargets mt) {
+    pair_rd_es_body<FH>(a, bx, pp, sel, partials, m, mt);
+}
+
 // LJ long-range correction: pair part over all non-frozen pairs with eps_ij*sig_ij != 0
 // (same-molecule pairs INCLUDED, lj.c:56-83) + per-atom self part (lj.c:85-107).  Depends only
 // on parameters and the volume, so it is evaluated at upload / box change, like the
@@ -362,17 +369,16 @@ __global__ __launch_bounds__(256) void ewald_self_kernel(DevAtoms a, double ewal
 //                         the chunks in order: U_recip up to the 4 pi / V factor).
 // ---------------------------------------------------------------------------------------------
 constexpr int kRecipWaves = 4;
-__global__ __launch_bounds__(64 * kRecipWaves) void recip_partial_kernel(DevAtoms a, const KVec *__restrict__ kv, int nk,
-                                                                          DirtyBlocks sel, double2 *__restrict__ part) {
+// (m: the step's move when the launch that runs this body also applies it -- pair_recip_kernel below)
+__device__ __forceinline__ void recip_partial_body(const DevAtoms &a, const KVec *__restrict__ kv, int nk,
+                                                   const DirtyBlocks &sel, double2 *__restrict__ part, const MoveList &m) {
     const int b = (sel.n > 0) ? sel.blk[blockIdx.y] : (int)blockIdx.y;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     __shared__ double sx[kWave], sy[kWave], sz[kWave], sq[kWave];
     __shared__ double2 red[kRecipWaves][kWave];
     if (w == 0) {
         const int j = b * kWave + lane;
-        sx[lane] = a.x[j];
-        sy[lane] = a.y[j];
-        sz[lane] = a.z[j];
+        moved_position(a, m, j, sx[lane], sy[lane], sz[lane]);
         sq[lane] = ((a.flags[j] & kValid) && !(a.flags[j] & kFrozen)) ? a.q[j] : 0.0;
     }
     __syncthreads();
@@ -399,6 +405,35 @@ __global__ __launch_bounds__(64 * kRecipWaves) void recip_partial_kernel(DevAtom
         }
         part[(size_t)b * nk + k] = make_double2(r, i);
     }
+}
+
+__global__ __launch_bounds__(64 * kRecipWaves) void recip_partial_kernel(DevAtoms a, const KVec *__restrict__ kv, int nk,
+                                                                          DirtyBlocks sel, double2 *__restrict__ part) {
+    MoveList m;
+    m.n = 0;
+    recip_partial_body(a, kv, nk, sel, part, m);
+}
+
+// The pair kernel and the reciprocal-space partials of the same blocks as ONE launch: the two are independent (each reads
+// coordinates and parameters only), so the partial structure factors ride in a second z-slice of the pair kernel's grid
+// -- workgroup (x, y, 1) is recip_partial_kernel's workgroup (x, y), run by the first 4 of its 8 waves -- instead of
+// being a launch of their own behind it: one launch less per LJ + Ewald step (a quarter of the S-ES(1024) step).  When the
+// launch carries the step's move, the reciprocal role takes moved positions from the list too.
+struct RecipJob {
+    const KVec *kv;
+    int nk;
+    double2 *part;
+};
+template <int FH>
+__global__ __launch_bounds__(64 * kPairWaves) void pair_recip_kernel(DevAtoms a, DevBox bx, PairParams pp, DirtyBlocks sel,
+                                                                      double *__restrict__ partials, MoveList m,
+                                                                      MoveTargets mt, RecipJob rj) {
+    if (blockIdx.z == 1) {
+        if ((int)blockIdx.x * kWave >= rj.nk || threadIdx.x >= 64 * kRecipWaves) return;  // (whole waves leave)
+        recip_partial_body(a, rj.kv, rj.nk, sel, rj.part, m);
+        return;
+    }
+    pair_rd_es_body<FH>(a, bx, pp, sel, partials, m, mt);
 }
 
 constexpr int kRecipGroups = 16;

@@ -826,7 +826,7 @@ def test_resident_solver_is_only_used_where_it_applies_and_falls_back_when_a_han
 
 
 def test_sweep_and_move_options_are_bit_neutral():
-    """sweep_alternate / sweep_nt / fuse_moves / fuse_field / side_moves / split_record change how the step is executed, not one bit of what it
+    """sweep_alternate / sweep_nt / fuse_moves / fuse_field / fuse_recip / side_moves / split_record change how the step is executed, not one bit of what it
     computes (each energy term is compared: side_moves decides which stream's kernels learn of the move how)."""
     s = load("pcn61_bssp_4096") if os.path.exists(os.path.join(GOLD, "pcn61_bssp_4096.npz")) else synth.s_pol(2048)
     n = len(s["charge"])
@@ -834,7 +834,7 @@ def test_sweep_and_move_options_are_bit_neutral():
              feynman_hibbs_order=4, polar_palmo=1)
     movable = np.where(~s["frozen"].astype(bool))[0]
     ref = None
-    for opts in ({}, {"sweep_alternate": 0}, {"sweep_nt": 1}, {"fuse_moves": 0}, {"fuse_field": 0}, {"side_moves": 0}, {"split_record": 0},
+    for opts in ({}, {"sweep_alternate": 0}, {"sweep_nt": 1}, {"fuse_moves": 0}, {"fuse_field": 0}, {"fuse_recip": 0}, {"side_moves": 0}, {"split_record": 0},
                  {"sweep_alternate": 0, "fuse_moves": 0, "sweep_nt": 0}):
         e = engine.Engine(n)
         e.load_system(s, p)
@@ -860,6 +860,35 @@ def test_sweep_and_move_options_are_bit_neutral():
         else:
             assert hist == ref[0], opts
             assert np.array_equal(mu, ref[1]), opts
+
+def test_pair_and_reciprocal_partials_in_one_launch_are_bit_neutral():
+    """LJ + Ewald without polarization: the step's move, the pair tiles and the reciprocal-space partials of the moved
+    blocks travel in ONE launch (pair_recip_kernel; option fuse_recip).  Same bits as the launches one by one, through
+    moves and restores, for cubic and sheared cells."""
+    for s in (synth.s_es(1024), dict(synth.s_es(1024), basis=synth.s_es(1024)["basis"] + np.array([[0, 0, 0], [1.5, 0, 0], [0.7, -0.9, 0]]))):
+        p = dict(synth.FLAGS_ES)
+        out = []
+        for fuse in (1, 0):
+            e = engine.Engine(1024)
+            e.load_system(s, p)
+            e.set_option("fuse_recip", fuse)
+            terms = ("energy", "rd_energy", "coulombic_energy", "es_recip", "es_real")
+            r = e.energy()
+            hist = [tuple(r[t] for t in terms)]
+            rng = np.random.default_rng(3)
+            for step in range(6):
+                first = 2 * int(rng.integers(0, 512))
+                e.update_atoms(first, s["pos"][first:first + 2] + rng.normal(scale=0.1, size=3))
+                r = e.energy()
+                hist.append(tuple(r[t] for t in terms))
+                if step % 2:
+                    e.update_atoms(first, s["pos"][first:first + 2])
+            e.close()
+            out.append(hist)
+        assert out[0] == out[1]
+        s2 = dict(s)
+        check_energies(run_engine(s2, p), oracle.energy(s2, p))
+
 
 def test_ragged_sizes_and_padding():
     """n not a multiple of the tile sizes, down to a single molecule."""
