@@ -143,7 +143,8 @@ void mpmc_hip_destroy(mpmc_hip_ctx *ctx);
  *                          0 = the host sorts the ranking metric in every call;
  *   "rank_late"           (default 1): in a speculative polar_gs_ranked call the side stream's ranking kernels and
  *                          ranked-view maintenance are enqueued behind the first sweep's launches, so the main stream's
- *                          own first kernels are not kept waiting for the host (0 = in front; A/B, same results);
+ *                          own first kernels are not kept waiting for the host (0 = in front; 2 = the metric's four kernels behind the
+ *                          main stream's first launches, the view maintenance behind the sweep: measured the same; A/B);
  *   "resident_jacobi"     (default 1): fixed-count Jacobi / SOR / ESOR / Palmo solves of views of up to 21 blocks
  *                          (1 344 polarizable sites) run as ONE launch with the coefficient tiles held in registers
  *                          (jacobi_resident_kernel); a launch that gives up on a hand-off (device shared with another
