@@ -8,7 +8,9 @@
 //   [es]     real-space part in the same pair kernel, reciprocal kernel, self term       side stream
 // Everything pairwise is resident and updated incrementally after a move (coefficients, tile partial
 // sums of the pair / field / LRC kernels); the only host<->device traffic per call is the moved
-// molecule's coordinates in (kernel arguments) and a 16-double result record out (mapped host memory).
+// molecule's coordinates in (kernel arguments) and a 16-double result record out (mapped host memory; in the
+// Jacobi-type modes in two parts, one per stream, so that a steady-state step has no cross-stream event at all: the
+// side stream takes the move from its own kernel arguments and publishes its own slots).
 // The reference plugin re-allocated and re-uploaded everything per call (polar_cuda_pcg.cu:221-401).
 #include "../../include/mpmc_hip.h"
 

@@ -37,6 +37,11 @@
 // mpmc_hip_energy_end() repeats the evaluation on the multi-launch path and switches this kernel off for the context.
 // All workgroups must be co-resident (each tile group waits for all finishers of its blocks and vice versa): the host
 // sizes the grid from the CU count and does not use this path when another context of the process shares the device.
+//
+// Two kernels: jacobi_resident_kernel (tile groups + one finisher workgroup per block, as described above; views of 17
+// to 21 blocks) and, at the end of the file, jacobi_folded_kernel (views of up to 16 blocks, the engine's default there):
+// no finisher workgroups -- every tile workgroup finishes its own two blocks, ONE hand-off per sweep instead of two,
+// three rotating partial-sum buffers re-armed by their producers.  Both are bit-identical to the multi-launch path.
 #pragma once
 #include "device_common.h"
 #include "kernels_coef.h"
