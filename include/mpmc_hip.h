@@ -169,7 +169,9 @@ void mpmc_hip_destroy(mpmc_hip_ctx *ctx);
  *                          for it in front of its publish launch; 0 = join event + one record (A/B; same bits);
  *   "side_moves"          (default 1): in such a step the LJ / Ewald stream's pair kernel applies the same move for itself
  *                          (both streams write the same coordinates, neither reads a moved atom from memory), so no event
- *                          is recorded between the main stream's first two launches; 0 = fork event (A/B; same bits);
+ *                          is recorded between the main stream's first two launches; where the move is applied by
+ *                          apply_moves_kernel (Gauss-Seidel modes, precision mode) the side stream runs that kernel too, in
+ *                          front of its first launch; 0 = fork event (A/B; same bits);
  *   "resident_stamps" / "sweep_ablate": diagnostics (in-kernel time line of the resident launch; timing-only ablations
  *                          of the sweep: results are wrong); "resident_fault": test hook (a lost hand-off);
  *   "gs_stamps"           diagnostic: the next `value` Gauss-Seidel sweeps print in-kernel time stamps per block;

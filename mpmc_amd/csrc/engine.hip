@@ -217,6 +217,8 @@ struct mpmc_hip_ctx {
     bool moves_deferred = false;           // pending moves not yet applied in the call being enqueued
     bool side_carry = false;               // ... and the side stream's pair kernel carries the same move itself (side_moves):
     MoveList side_moves;                   //     no fork event between the two streams in a steady-state polarizable step
+    MoveList side_apply;                   // a move the main stream applied with apply_moves_kernel: the side stream applies it
+    bool side_applied = false;             //     too (a launch of its own, in front of its first kernel) instead of waiting for an event
     int opt_split_record = 1;              // "split_record": the side stream publishes its own part of the result record
     bool call_split = false;               // the call in flight did (energy_end waits for both sequence numbers)
     int opt_fuse_recip = 1;                // "fuse_recip": the reciprocal-space partials ride in the pair kernel's launch
@@ -919,6 +921,11 @@ extern "C" int mpmc_hip_upload(mpmc_hip_ctx *c, int n, const double *x, const do
 }
 
 // apply the queued single-molecule moves (kept in order with any staged copies)
+// What the side stream does before its first kernel that reads coordinates: apply the step's move itself (the same
+// apply_moves_kernel with the same list: same bits into the same arrays as the main stream's launch; neither stream reads
+// a moved coordinate before its own writer) -- or, when the move reached the device another way (edits, staged copies),
+// wait for the event the main stream recorded behind it.
+static void side_wait_for_moves(mpmc_hip_ctx *c, hipStream_t s);
 static int flush_moves(mpmc_hip_ctx *c) {
     if (c->pending.n > 0) {
         SweepView &v0 = c->view[0];
@@ -927,6 +934,19 @@ static int flush_moves(mpmc_hip_ctx *c) {
         c->pending.n = 0;
     }
     return 0;
+}
+
+static void side_wait_for_moves(mpmc_hip_ctx *c, hipStream_t s) {
+    if (c->side_apply.n > 0) {
+        SweepView &v0 = c->view[0];
+        hipLaunchKernelGGL(apply_moves_kernel, dim3(1), dim3(64), 0, s, c->side_apply, c->d_x, c->d_y, c->d_z,
+                           (const int *)v0.d_slot, v0.px, v0.py, v0.pz);
+        c->side_apply.n = 0;
+        c->side_applied = true;
+        return;
+    }
+    if (c->side_applied) return;  // (already on this stream, earlier in the call)
+    hipStreamWaitEvent(s, c->ev_fork, 0);
 }
 
 extern "C" int mpmc_hip_update_atoms(mpmc_hip_ctx *c, int first, int count, const double *x, const double *y,
@@ -1725,7 +1745,15 @@ static int enqueue_direct(mpmc_hip_ctx *c) {
     // (The long-range-correction and self-term kernels in front of it read parameters only.)
     c->moves_in_pair = !c->moves_deferred && c->opt_fuse_moves && c->pending.n > 0 && c->graph_mode == GM_DIRECT &&
                        !c->opt_graph && !(!c->par.rd_only && c->par.polarization) && !c->dirty_atoms.empty();
-    if (!c->moves_deferred && !c->moves_in_pair && flush_moves(c)) return -1;
+    c->side_apply.n = 0;
+    c->side_applied = false;
+    if (!c->moves_deferred && !c->moves_in_pair) {
+        const mpmc_hip_params &Pm = c->par;
+        if (c->opt_side_moves && c->pending.n > 0 && c->opt_overlap && !Pm.rd_only && Pm.polarization &&
+            c->graph_mode == GM_DIRECT && !c->opt_graph)
+            c->side_apply = c->pending;  // (the side stream applies it too: no fork event, see side_wait_for_moves)
+        if (flush_moves(c)) return -1;
+    }
     // (the pair kernel is launched whenever an atom moved; the long-range-correction kernels in front of it read
     //  parameters only)
     c->side_carry = c->moves_deferred && c->opt_side_moves && !c->dirty_atoms.empty() && c->pending.n <= kMaxMoves;
@@ -1749,7 +1777,8 @@ static int enqueue_direct(mpmc_hip_ctx *c) {
     // modes keep the join (their ranking kernels share slots and streams with the chain), and so does graph capture.
     c->call_split = two_streams && c->opt_split_record && !P.polar_gs && !P.polar_gs_ranked && c->graph_mode == GM_DIRECT &&
                     !c->opt_graph;
-    if (two_streams && !c->moves_deferred) hipEventRecord(c->ev_fork, c->stream);  // (the side stream's wait is issued when it is fed)
+    if (two_streams && !c->moves_deferred && c->side_apply.n == 0)
+        hipEventRecord(c->ev_fork, c->stream);  // (the side stream's wait is issued when it is fed)
 
     const bool do_polar = !P.rd_only && P.polarization;
     // Enqueue order: the host needs ~3 us per launch and the polarization chain is the critical path, so
@@ -1765,7 +1794,7 @@ static int enqueue_direct(mpmc_hip_ctx *c) {
         side_done = true;
         side_rc = [&]() -> int {
         // after apply_moves: the new coordinates are in place (unless this stream's pair kernel brings the move itself)
-        if (two_streams && !(c->side_carry && c->side_moves.n > 0)) hipStreamWaitEvent(sb, c->ev_fork, 0);
+        if (two_streams && !(c->side_carry && c->side_moves.n > 0)) side_wait_for_moves(c, sb);
         // ---- LJ long-range correction: parameters + volume only => cached (lj.c:56-107)
         if (P.rd_lrc) {
             // depends on parameters, the volume and WHICH atoms exist -- not on coordinates: summed once, its

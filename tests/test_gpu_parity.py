@@ -438,11 +438,14 @@ def test_ranked_walk_is_speculated_and_repeated_when_the_metric_changes():
     s = synth.s_pol(640)
     p = dict(synth.FLAGS_POL_PRODUCTION)
     engs = []
-    for spec, late in ((1, 1), (1, 0), (0, 1)):  # (rank_late: when the speculative call's ranking work is enqueued)
+    # (rank_late: when the speculative call's ranking work is enqueued; side_moves: whether the side stream applies the
+    #  move itself or waits for an event behind the main stream's apply_moves_kernel)
+    for spec, late, side in ((1, 1, 1), (1, 0, 1), (0, 1, 1), (1, 1, 0)):
         e = engine.Engine(640)
         e.load_system(s, p)
         e.set_option("speculative_ranking", spec)
         e.set_option("rank_late", late)
+        e.set_option("side_moves", side)
         engs.append(e)
     pos = s["pos"].copy()
     target = pos[5 * 7:5 * 7 + 5].copy()  # molecule 7
@@ -474,7 +477,7 @@ def test_ranked_walk_is_speculated_and_repeated_when_the_metric_changes():
     assert not np.array_equal(orders[0], orders[1]) and np.array_equal(orders[1], orders[2])
     assert not np.array_equal(orders[2], orders[3]) and np.array_equal(orders[0], orders[4])
     redo = [e.timings()["spec_rank_redos"] for e in engs]
-    assert redo == [2, 2, 0]  # exactly the two calls whose metric changed were repeated; the host-sorted engine never
+    assert redo == [2, 2, 0, 2]  # exactly the two calls whose metric changed were repeated; the host-sorted engine never
     for e in engs:
         e.close()
 
