@@ -360,6 +360,52 @@ def test_incremental_updates_are_bit_identical_to_full_recomputation(pair_coeffi
         e.close()
 
 
+@pytest.mark.parametrize("field", [dict(polar_wolf=1), dict(polar_wolf=1, polar_wolf_alpha=0.13), dict(polar_ewald=1)])
+def test_fused_first_launch_with_wolf_and_ewald_fields(field):
+    """The move + coefficient update ride in the incremental static-field launch for the bare and Wolf fields
+    (field_coef_kernel<MODE>; the Ewald field keeps the coefficient update as a launch of its own).  A chain of moves and
+    restores with the fused launch equals, bit for bit, the chain with every launch on its own (fuse_field = fuse_moves =
+    side_moves = split_record = 0) and a from-scratch evaluation, and follows the oracle."""
+    s = synth.s_pol(1024)
+    p = dict(temperature=77.0, polarization=1, polar_damp=2.1304, polar_max_iter=4, polar_palmo=1)
+    p.update(field)
+    engs = []
+    for plain in (0, 1):
+        e = engine.Engine(1024)
+        e.load_system(s, p)
+        e.set_option("resident_jacobi", 0)
+        if plain:
+            for o in ("fuse_field", "fuse_moves", "side_moves", "split_record", "fuse_recip"):
+                e.set_option(o, 0)
+        engs.append(e)
+    pos = s["pos"].copy()
+    rng = np.random.default_rng(17)
+    terms = ("energy", "polarization_energy", "rd_energy", "coulombic_energy")
+    for step in range(6):
+        first = 5 * int(rng.integers(0, 1024 // 5))
+        new = pos[first:first + 5] + rng.normal(scale=0.15, size=3)
+        got = []
+        for e in engs:
+            e.update_atoms(first, new)
+            got.append(e.energy())
+        for t in terms:
+            assert got[0][t] == got[1][t], (step, t)
+        if step % 2:
+            for e in engs:
+                e.update_atoms(first, pos[first:first + 5])
+        else:
+            pos[first:first + 5] = new
+    got = [e.energy() for e in engs]
+    s2 = dict(s)
+    s2["pos"] = pos
+    fresh = run_engine(s2, p)
+    for t in terms:
+        assert got[0][t] == got[1][t] == fresh[t], t
+    check_energies(got[0], oracle.energy(s2, p))
+    for e in engs:
+        e.close()
+
+
 @pytest.mark.parametrize("persistent_gs", [1, 0])
 def test_ranked_gauss_seidel_chain_keeps_its_view_incrementally(persistent_gs):
     """Production flags (Wolf field, ranked Gauss-Seidel, Palmo, gamma 1.03): the ranked view's data (pair
