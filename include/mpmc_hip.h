@@ -141,6 +141,8 @@ void mpmc_hip_destroy(mpmc_hip_ctx *ctx);
  *   "speculative_ranking" (default 1): polar_gs_ranked calls are enqueued for the ranked walk of the previous call
  *                          and checked on the device (repeated with the host sorting when the metric changed);
  *                          0 = the host sorts the ranking metric in every call;
+ *   "fuse_tensor"         (default 1): Gauss-Seidel chain data after a move: the expanded sub-diagonal tiles ride in a
+ *                          second z-slice of the block-inverse launch (0 = gs_neighbor_tensor_kernel on its own; A/B);
  *   "rank_late"           (default 1): in a speculative polar_gs_ranked call the side stream's ranking kernels and
  *                          ranked-view maintenance are enqueued behind the first sweep's launches, so the main stream's
  *                          own first kernels are not kept waiting for the host (0 = in front; 2 = the metric's four kernels behind the

@@ -181,19 +181,18 @@ struct BlockList {
     int blk[kMaxBlockList];
 };
 
+// (rows: the tile's source atoms j = jw + 4 kk, kk = k0 .. k0 + nk - 1, jw = wave of a 256-thread workgroup)
 template <int ORTHO>
-__global__ __launch_bounds__(256) void gs_neighbor_tensor_kernel(const double2 *__restrict__ C, int ntld,
-                                                                  const double *__restrict__ px,
-                                                                  const double *__restrict__ py,
-                                                                  const double *__restrict__ pz, DevBox bx, BlockList sel,
-                                                                  double2 *__restrict__ Tnb) {
-    const int t = (sel.n > 0) ? sel.blk[blockIdx.x] : (int)blockIdx.x + 1;
+__device__ __forceinline__ void gs_neighbor_tensor_body(const double2 *__restrict__ C, int ntld, const double *__restrict__ px,
+                                                        const double *__restrict__ py, const double *__restrict__ pz,
+                                                        const DevBox &bx, int t, int k0, int nk, double2 *__restrict__ Tnb) {
     if (t < 1) return;
     const double2 *tile = C + coef_tile_index(t - 1, t, ntld) * (kCoefTile * kCoefTile);
     double2 *out = Tnb + (size_t)t * kTnbDouble2;
     const int i = threadIdx.x & 63;
     const double xi = px[64 * t + i], yi = py[64 * t + i], zi = pz[64 * t + i];
-    for (int j = threadIdx.x >> 6; j < 64; j += 4) {
+    for (int kk = k0; kk < k0 + nk; ++kk) {
+        const int j = (threadIdx.x >> 6) + 4 * kk;
         const int js = 64 * (t - 1) + j;
         // row atom of the tile = source j (block t-1), column atom = target i: element (l = j, s = (i - j) & 63)
         const double2 c = tile[((i - j) & 63) * 64 + j];
@@ -204,6 +203,16 @@ __global__ __launch_bounds__(256) void gs_neighbor_tensor_kernel(const double2 *
         out[(j * 3 + 1) * 64 + i] = make_double2(-3.0 * dx * dz * c5, -3.0 * dy * dy * c5 + c3);
         out[(j * 3 + 2) * 64 + i] = make_double2(-3.0 * dy * dz * c5, -3.0 * dz * dz * c5 + c3);
     }
+}
+
+template <int ORTHO>
+__global__ __launch_bounds__(256) void gs_neighbor_tensor_kernel(const double2 *__restrict__ C, int ntld,
+                                                                  const double *__restrict__ px,
+                                                                  const double *__restrict__ py,
+                                                                  const double *__restrict__ pz, DevBox bx, BlockList sel,
+                                                                  double2 *__restrict__ Tnb) {
+    const int t = (sel.n > 0) ? sel.blk[blockIdx.x] : (int)blockIdx.x + 1;
+    gs_neighbor_tensor_body<ORTHO>(C, ntld, px, py, pz, bx, t, 0, 16, Tnb);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -227,7 +236,18 @@ __global__ __launch_bounds__(64 * WAVES) void gs_block_inverse_kernel(const doub
                                                                 const double *__restrict__ py,
                                                                 const double *__restrict__ pz,
                                                                 const double *__restrict__ alpha, DevBox bx, BlockList sel,
-                                                                double *__restrict__ Minv) {
+                                                                double *__restrict__ Minv, BlockList nbt,
+                                                                double2 *__restrict__ Tnb) {
+    // (nbt.n > 0, WAVES = 4: the expanded sub-diagonal tiles of the same move -- gs_neighbor_tensor_kernel's work, which
+    //  depends on the coefficients only -- ride in a second z-slice of this launch, a quarter of a tile per workgroup,
+    //  instead of being a launch of their own behind it)
+    if (blockIdx.z == 1) {
+        if constexpr (WAVES == 4) {
+            const int u = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;
+            if (u < 4 * nbt.n) gs_neighbor_tensor_body<ORTHO>(C, ntld, px, py, pz, bx, nbt.blk[u >> 2], 4 * (u & 3), 4, Tnb);
+        }
+        return;
+    }
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *T6 = lds;                  // column b (0..62): offset 6 (63 b - b (b - 1) / 2), then [e][a - b - 1], a > b
     double *sx = lds + kGsPairs * 6;   // [64] x, y, z, alpha of the block
