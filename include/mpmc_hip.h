@@ -143,6 +143,8 @@ void mpmc_hip_destroy(mpmc_hip_ctx *ctx);
  *                          0 = the host sorts the ranking metric in every call;
  *   "fuse_tensor"         (default 1): Gauss-Seidel chain data after a move: the expanded sub-diagonal tiles ride in a
  *                          second z-slice of the block-inverse launch (0 = gs_neighbor_tensor_kernel on its own; A/B);
+ *   "gs_fold_upper"       (default 1): the chain kernel's workgroups add up pair_upper_kernel's row sums of their own
+ *                          blocks (0 = pair_upper_finish_kernel as a launch of its own in front of every chain launch);
  *   "rank_late"           (default 1): in a speculative polar_gs_ranked call the side stream's ranking kernels and
  *                          ranked-view maintenance are enqueued behind the first sweep's launches, so the main stream's
  *                          own first kernels are not kept waiting for the host (0 = in front; 2 = the metric's four kernels behind the

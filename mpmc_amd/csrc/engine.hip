@@ -223,6 +223,7 @@ struct mpmc_hip_ctx {
     bool call_split = false;               // the call in flight did (energy_end waits for both sequence numbers)
     int opt_fuse_recip = 1;                // "fuse_recip": the reciprocal-space partials ride in the pair kernel's launch
     bool recip_fused = false;              // ... and did, in the call being enqueued
+    int opt_gs_fold_upper = 1;             // "gs_fold_upper": the chain's workgroups add up pair_upper_kernel's row sums themselves
     int opt_fuse_tensor = 1;               // "fuse_tensor": a move's sub-diagonal tensor tiles ride in the block-inverse launch
     int opt_rank_late = 1;                 // "rank_late": polar_gs_ranked's side-stream ranking work is enqueued behind the first sweep
     int opt_fuse_field = 1;                // "fuse_field": the move + coefficient update ride inside the field kernel's launch
@@ -541,6 +542,8 @@ extern "C" int mpmc_hip_set_option(mpmc_hip_ctx *c, const char *name, int value)
         c->opt_split_record = value;  // 0: the main stream waits for the side stream (join event) and publishes everything
     else if (!strcmp(name, "fuse_recip"))
         c->opt_fuse_recip = value;  // 0: recip_partial_kernel as a launch of its own behind the pair kernel
+    else if (!strcmp(name, "gs_fold_upper"))
+        c->opt_gs_fold_upper = value;  // 0: pair_upper_finish_kernel as a launch of its own in front of every chain launch
     else if (!strcmp(name, "fuse_tensor"))
         c->opt_fuse_tensor = value;  // 0: gs_neighbor_tensor_kernel as a launch of its own (A/B; same bits)
     else if (!strcmp(name, "rank_late"))

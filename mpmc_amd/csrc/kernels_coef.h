@@ -585,7 +585,17 @@ __global__ __launch_bounds__(64 * kCoefWaves) void pair_upper_kernel(const doubl
                                                                        const double *__restrict__ y,
                                                                        const double *__restrict__ z,
                                                                        const double *__restrict__ mu, DevBox bx,
-                                                                       double *__restrict__ Srow, int rev) {
+                                                                       double *__restrict__ Srow, int rev, int arm_nb,
+                                                                       double *__restrict__ mu_new,
+                                                                       unsigned *__restrict__ gsflags) {
+    // (arm_nb > 0: the chain kernel behind this launch adds up the row sums itself -- no pair_upper_finish_kernel -- so the
+    //  hand-off buffer is armed here: workgroup b < arm_nb fills block b's 192 words with the sentinel, workgroup 0 zeroes
+    //  the ticket counter; the error word, gsflags[1], is sticky for the whole energy() call and is NOT touched)
+    if (arm_nb > 0) {
+        if ((int)blockIdx.x < arm_nb && threadIdx.x < 192)
+            mu_new[192 * blockIdx.x + threadIdx.x] = __longlong_as_double(0x7ff8dead7ff8deadll);
+        if (blockIdx.x == 0 && threadIdx.x == 0) gsflags[0] = 0u;
+    }
     int ti, tj;
     {   // XCD-aware order, alternating from sweep to sweep (see pair_sweep_kernel)
         const int ntiles = nt * (nt + 1) / 2;

@@ -81,6 +81,10 @@ struct GsChain {
     int ablate;        // TIMING-ONLY ablations (option "gs_ablate", results are wrong): bit 0 no source loop, bit 1 no
                        // tile loads, bit 2 no polls in the source loop, bit 3 the critical section only republishes
     unsigned long long *stamps;  // diagnostic (option "gs_stamps"): [nb][16] s_memrealtime stamps of one sweep, or null
+    // Srow != null: the upper-triangle row sums of pair_upper_kernel are added up HERE (pair_upper_finish_kernel's
+    // arithmetic in its order, by the block's own workgroup while it waits for its turn) and `y` is not read
+    const double *Srow;
+    int nt_upper;
     // End-of-sweep bookkeeping of the block (what gs_finish_kernel does as a launch of its own: E_induced, the (S)OR mix,
     // RRMS, max change), done by the block's workgroup AFTER it has published -- off the chain's critical path.
     struct Finish {
@@ -344,6 +348,48 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
     GS_STAMP(0);
     if (p.stamps && tid == 0) p.stamps[(size_t)t * 16 + 12] = __builtin_amdgcn_s_memtime();  // shader clock, for the effective MHz
 
+    // ---- yU of this block = - sum_{tj >= t} Srow[tj][block t]: pair_upper_finish_kernel's sum, term for term (16 groups
+    // of terms u = g, g + 16, ...; groups added in order), through the staging area before M_t moves in
+    double f_yu_own = 0.0;
+    if (p.Srow) {
+        double *part = sM;  // [16][3][64]
+        const int nterm = p.nt_upper - t;
+        const size_t ncol = 3 * (size_t)kCoefTile * p.nt_upper;
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+            const int g = w + kChainWaves * gi;
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+            for (int u0 = g; u0 < nterm; u0 += 4 * kCoefFinishGroups) {
+                double v[4][3];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int u = u0 + k * kCoefFinishGroups;
+                    const bool on = u < nterm;
+                    const double *q = p.Srow + (size_t)(t + (on ? u : 0)) * ncol + 192 * t + lane;
+                    v[k][0] = on ? q[0] : 0.0;
+                    v[k][1] = on ? q[64] : 0.0;
+                    v[k][2] = on ? q[128] : 0.0;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    s0 += v[k][0];
+                    s1 += v[k][1];
+                    s2 += v[k][2];
+                }
+            }
+            part[(g * 3 + 0) * 64 + lane] = s0;
+            part[(g * 3 + 1) * 64 + lane] = s1;
+            part[(g * 3 + 2) * 64 + lane] = s2;
+        }
+        __syncthreads();
+        if (tid < 192) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < kCoefFinishGroups; ++k) acc += part[(k * 3 + w) * 64 + lane];
+            f_yu_own = -acc;
+        }
+        __syncthreads();  // (M_t is staged over these words next)
+    }
     // ---- stage M_t (folded layout, 16-B loads) and the target block's coordinates
     {
         const double2 *src = reinterpret_cast<const double2 *>(p.Minv + (size_t)t * kMinvDoubles);
@@ -493,7 +539,7 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
         const int k = 64 * t + lane;
         f_al = p.alpha[k];
         f_es = p.es[3 * k + w];
-        f_yu = p.y[3 * k + w];
+        f_yu = p.Srow ? f_yu_own : p.y[3 * k + w];
     }
     double f_v = 0.0;
     // This wave's share of the inverse, LDS -> registers, BEFORE the hand-off arrives: 18 sixteen-byte reads per lane

@@ -486,7 +486,8 @@ def test_ranked_walk_is_speculated_and_repeated_when_the_metric_changes():
     engs = []
     # (rank_late: when the speculative call's ranking work is enqueued; side_moves: whether the side stream applies the
     #  move itself or waits for an event behind the main stream's apply_moves_kernel)
-    # (the last engine also launches the expanded sub-diagonal tiles on their own: fuse_tensor = 0)
+    # (the last engine also launches the expanded sub-diagonal tiles and the upper-triangle row sums on their own:
+    #  fuse_tensor = gs_fold_upper = 0)
     for spec, late, side in ((1, 1, 1), (1, 0, 1), (0, 1, 1), (1, 1, 0)):
         e = engine.Engine(640)
         e.load_system(s, p)
@@ -494,6 +495,7 @@ def test_ranked_walk_is_speculated_and_repeated_when_the_metric_changes():
         e.set_option("rank_late", late)
         e.set_option("side_moves", side)
         e.set_option("fuse_tensor", side)
+        e.set_option("gs_fold_upper", side)
         engs.append(e)
     pos = s["pos"].copy()
     target = pos[5 * 7:5 * 7 + 5].copy()  # molecule 7
