@@ -143,6 +143,9 @@ void mpmc_hip_destroy(mpmc_hip_ctx *ctx);
  *                          0 = the host sorts the ranking metric in every call;
  *   "fuse_tensor"         (default 1): Gauss-Seidel chain data after a move: the expanded sub-diagonal tiles ride in a
  *                          second z-slice of the block-inverse launch (0 = gs_neighbor_tensor_kernel on its own; A/B);
+ *   "rank_view_side"      (default 1): polar_gs_ranked calls in which the host sorts the metric (after a grand-canonical
+ *                          edit, or when the speculated walk was wrong): the ranked view is (re)built on the side
+ *                          stream beside the first sweep instead of on the main stream behind it (0 = main; A/B);
  *   "gs_fold_upper"       (default 1): the chain kernel's workgroups add up pair_upper_kernel's row sums of their own
  *                          blocks (0 = pair_upper_finish_kernel as a launch of its own in front of every chain launch);
  *   "rank_late"           (default 1): in a speculative polar_gs_ranked call the side stream's ranking kernels and

@@ -223,6 +223,7 @@ struct mpmc_hip_ctx {
     bool call_split = false;               // the call in flight did (energy_end waits for both sequence numbers)
     int opt_fuse_recip = 1;                // "fuse_recip": the reciprocal-space partials ride in the pair kernel's launch
     bool recip_fused = false;              // ... and did, in the call being enqueued
+    int opt_rank_view_side = 1;            // "rank_view_side": a host-sorted ranked view is (re)built on the side stream
     int opt_gs_fold_upper = 1;             // "gs_fold_upper": the chain's workgroups add up pair_upper_kernel's row sums themselves
     int opt_fuse_tensor = 1;               // "fuse_tensor": a move's sub-diagonal tensor tiles ride in the block-inverse launch
     int opt_rank_late = 1;                 // "rank_late": polar_gs_ranked's side-stream ranking work is enqueued behind the first sweep
@@ -542,6 +543,8 @@ extern "C" int mpmc_hip_set_option(mpmc_hip_ctx *c, const char *name, int value)
         c->opt_split_record = value;  // 0: the main stream waits for the side stream (join event) and publishes everything
     else if (!strcmp(name, "fuse_recip"))
         c->opt_fuse_recip = value;  // 0: recip_partial_kernel as a launch of its own behind the pair kernel
+    else if (!strcmp(name, "rank_view_side"))
+        c->opt_rank_view_side = value;  // 0: on the main stream, behind the first sweep (A/B; same results)
     else if (!strcmp(name, "gs_fold_upper"))
         c->opt_gs_fold_upper = value;  // 0: pair_upper_finish_kernel as a launch of its own in front of every chain launch
     else if (!strcmp(name, "fuse_tensor"))
@@ -1384,7 +1387,8 @@ static int ensure_coef_scratch(SweepView &v, int nt) {
     return 0;
 }
 
-static int ensure_view_coef(mpmc_hip_ctx *c, SweepView &v, int nt) {
+static int ensure_view_coef(mpmc_hip_ctx *c, SweepView &v, int nt, hipStream_t st) {
+    (void)c;
     // sized for every tile the view can grow to (insert_molecule appends to the view), so the tile stride
     // never changes; tiles start out as zeros (= "no pair"), which is what unused slots must read as
     const int ntld = std::max(nt, (v.cap + kCoefTile - 1) / kCoefTile);
@@ -1394,8 +1398,9 @@ static int ensure_view_coef(mpmc_hip_ctx *c, SweepView &v, int nt) {
         v.C = nullptr;
         v.Ccap = 0;
         HIPCHK(hipMalloc((void **)&v.C, need * sizeof(double2)));
-        // on the engine's stream: the non-blocking streams do not order themselves after the null stream
-        HIPCHK(hipMemsetAsync(v.C, 0, need * sizeof(double2), c->stream));
+        // on the stream that builds the view (the non-blocking streams do not order themselves after the null stream; and
+        // a ranked view may be built on the side stream while the main one is busy: a memset queued THERE would come last)
+        HIPCHK(hipMemsetAsync(v.C, 0, need * sizeof(double2), st));
         v.Ccap = need;
         v.ntld = ntld;
         v.C_valid = false;
@@ -1404,13 +1409,14 @@ static int ensure_view_coef(mpmc_hip_ctx *c, SweepView &v, int nt) {
 }
 
 // cached block inverses + expanded sub-diagonal tiles of the Gauss-Seidel chain, sized for the view's capacity
-static int ensure_view_chain(mpmc_hip_ctx *c, SweepView &v) {
+static int ensure_view_chain(mpmc_hip_ctx *c, SweepView &v, hipStream_t st) {
+    (void)c;
     if (v.Minv && v.Tnb) return 0;
     const size_t nbcap = (size_t)(v.cap + 63) / 64;
     HIPCHK(hipMalloc((void **)&v.Minv, nbcap * kMinvDoubles * sizeof(double)));
     HIPCHK(hipMalloc((void **)&v.Tnb, nbcap * kTnbDouble2 * sizeof(double2)));
     // the folded inverse has 32 padding lanes per block that no build writes: they must read as zero
-    HIPCHK(hipMemsetAsync(v.Minv, 0, nbcap * kMinvDoubles * sizeof(double), c->stream));
+    HIPCHK(hipMemsetAsync(v.Minv, 0, nbcap * kMinvDoubles * sizeof(double), st));
     v.M_epoch = 0;
     return 0;
 }
