@@ -351,12 +351,39 @@ def main():
     # ---- walker pooling through the C ABI: rank 0 makes the RCCL id, the launcher's process group hands it round
     rccl_ranks = 1
     pooled = dist is not None  # under a launcher the collective runs also with one rank (same code path as N ranks)
+    collective = "none (single walker, no launcher)"
+    reducer = None
     if pooled:
-        ids = [host.walkers_unique_id() if rank == 0 else None]
+        # Every rank tries the C ABI's communicator; they then agree (one all-reduce of the launcher's group) on whether
+        # ALL of them have it.  If any could not (librccl missing, an init error), all fall back together to the
+        # launcher's own all-reduce and the line says so -- a labelled number instead of a crashed scaling run.
+        err = ""
+        try:
+            ids = [host.walkers_unique_id() if rank == 0 else None]
+        except Exception as e:  # noqa: BLE001 -- reported in the line
+            ids, err = [None], repr(e)
         dist.broadcast_object_list(ids, src=0)
-        chain.walkers_init(world, rank, ids[0])
-        rccl_ranks = world
-    avg = WalkerAverages(reducer=AbiReducer(chain) if pooled else None)
+        if ids[0] is not None and not err:
+            try:
+                chain.walkers_init(world, rank, ids[0])
+            except Exception as e:  # noqa: BLE001
+                err = repr(e)
+        else:
+            err = err or "rank 0 could not make the RCCL id"
+        okt = torch.tensor([0.0 if err else 1.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        if float(okt.item()) > 0.5:
+            reducer = AbiReducer(chain)
+            rccl_ranks = world
+            collective = "mpmc_hip_allreduce_observables_begin/_end (C ABI, RCCL) every corrtime"
+        else:
+            from mpmc_amd.walkers import TorchReducer
+
+            reducer = TorchReducer(dist, device=dev)
+            rccl_ranks = 0
+            collective = ("torch.distributed all_reduce (nccl = RCCL) every corrtime -- FALLBACK: the C ABI's communicator "
+                          "could not be made on every rank (%s)" % (err or "another rank failed"))
+    avg = WalkerAverages(reducer=reducer)
 
     for var, opt in (("MPMC_OVERLAP", "overlap_streams"), ("MPMC_SIDE_AFTER", "side_after"),
                      ("MPMC_STEP_GRAPH", "step_graph"), ("MPMC_SYM_MODE", "sym_mode"), ("MPMC_GS_DEBUG", "persistent_gs"),
@@ -533,8 +560,7 @@ def main():
                                     "; energy() incremental (bit-identical to full)"),
                        "n_atoms": n, "n_polarizable": n_pol, "walkers": world * W, "corrtime": args.corrtime,
                        "parallelism": "%d independent walkers, %d per GPU" % (world * W, W),
-                       "collective": ("mpmc_hip_allreduce_observables_begin/_end (C ABI, RCCL) every corrtime" if pooled
-                                      else "none (single walker, no launcher)"),
+                       "collective": collective,
                        "rccl_ranks": rccl_ranks},
             "full_rebuild_steps_per_s": full_rebuild_rate,
             "roofline": {"kernel": kernel_name + " (Thole field / dipole sweep)", "bound": "hbm",
