@@ -269,6 +269,12 @@ int mpmc_hip_allreduce_observables(mpmc_hip_comm *comm, double *values, int coun
  * energy() calls of the next corrtime interval can run in between.  One collective in flight per communicator. */
 int mpmc_hip_allreduce_observables_begin(mpmc_hip_comm *comm, const double *values, int count);
 int mpmc_hip_allreduce_observables_end(mpmc_hip_comm *comm, double *values);
+/* The MPI_Gather itself (mc.c:431: MPI_Gather(snd_strct, 1, msgtype, rcv_strct, ...)): every walker contributes a
+ * record of `bytes` bytes (observables_t + avg_nodestats_t [+ histogram, sorbate info], mc.c:225-227) and receives
+ * the records of all walkers in rank order -- nranks * bytes bytes -- so that whichever rank acts as root can run
+ * update_root_averages() per walker (mc.c:443-476) unchanged.  An all-gather over xGMI; blocking, like the call
+ * it replaces; `bytes` must be the same on every rank. */
+int mpmc_hip_gather_observables(mpmc_hip_comm *comm, const void *record, int bytes, void *records);
 void mpmc_hip_comm_destroy(mpmc_hip_comm *comm);
 
 #ifdef __cplusplus

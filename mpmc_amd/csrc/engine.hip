@@ -269,6 +269,10 @@ struct mpmc_hip_ctx {
     unsigned long long config_rev = 1;   // bumped by everything that changes what an energy() call enqueues
     int eligible_streak = 0;             // consecutive calls that met graph_eligible()
     bool staged_copies = false;          // coordinates reached the device outside the MoveList since the last call
+    bool main_writes = false;            // the MAIN stream was given writes of coordinates / parameters / the slot map outside
+                                         // the MoveList since the last call (staged copies, an upload, edits, a new sweep
+                                         // order): the side stream must then wait for an event recorded behind them -- it may
+                                         // not just apply the queued move for itself (side_apply / side_carry)
     unsigned long long graph_launches = 0;
     double graph_update_s = 0.0, graph_launch_s = 0.0;
     bool call_polar = false, call_timed = false;
@@ -997,6 +1001,7 @@ extern "C" int mpmc_hip_update_atoms(mpmc_hip_ctx *c, int first, int count, cons
     } else if ((size_t)(3 * count) <= c->stage_cap) {
         if (flush_moves(c)) return -1;
         c->staged_copies = true;
+        c->main_writes = true;
         c->view[0].pos_valid = false;
         // small delta (one molecule): stage in pinned memory so the copies are truly asynchronous and the
         // caller's buffers are free at once; the ring is recycled after the next energy() has synchronised
@@ -1015,6 +1020,7 @@ extern "C" int mpmc_hip_update_atoms(mpmc_hip_ctx *c, int first, int count, cons
     } else {
         if (flush_moves(c)) return -1;
         c->staged_copies = true;
+        c->main_writes = true;
         c->view[0].pos_valid = false;
         HIPCHK(hipMemcpyAsync(c->d_x + first, x, b, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(c->d_y + first, y, b, hipMemcpyHostToDevice, c->stream));
@@ -1074,6 +1080,7 @@ static int launch_edits(mpmc_hip_ctx *c, const EditList &ed) {
     t.palpha = v0.palpha;
     t.pflags = v0.pflags;
     if (flush_moves(c)) return -1;  // keep the order of the caller's operations
+    c->main_writes = true;
     hipLaunchKernelGGL(apply_edits_kernel, dim3(1), dim3(64), 0, c->stream, ed, t);
     HIPCHK(hipGetLastError());
     return 0;
@@ -1233,6 +1240,7 @@ extern "C" int mpmc_hip_set_sweep_order(mpmc_hip_ctx *c, int count, const int *s
     }
     HIPCHK(hipSetDevice(c->device));
     if (flush_moves(c)) return -1;  // queued moves were addressed through the old view
+    c->main_writes = true;          // (the slot map below; and a flushed move is a main-stream write the side stream has not seen)
     // how far the new order agrees with the old one: the blocks in front of the first difference keep their data
     int p0 = 0;
     {
@@ -1761,14 +1769,15 @@ static int enqueue_direct(mpmc_hip_ctx *c) {
     c->side_applied = false;
     if (!c->moves_deferred && !c->moves_in_pair) {
         const mpmc_hip_params &Pm = c->par;
-        if (c->opt_side_moves && c->pending.n > 0 && c->opt_overlap && !Pm.rd_only && Pm.polarization &&
+        if (c->opt_side_moves && !c->main_writes && c->pending.n > 0 && c->opt_overlap && !Pm.rd_only && Pm.polarization &&
             c->graph_mode == GM_DIRECT && !c->opt_graph)
             c->side_apply = c->pending;  // (the side stream applies it too: no fork event, see side_wait_for_moves)
         if (flush_moves(c)) return -1;
     }
     // (the pair kernel is launched whenever an atom moved; the long-range-correction kernels in front of it read
     //  parameters only)
-    c->side_carry = c->moves_deferred && c->opt_side_moves && !c->dirty_atoms.empty() && c->pending.n <= kMaxMoves;
+    c->side_carry = c->moves_deferred && c->opt_side_moves && !c->main_writes && !c->dirty_atoms.empty() &&
+                    c->pending.n <= kMaxMoves;
     c->side_moves.n = 0;
     if (is_timed_call(c)) hipEventRecord(c->ev_first, c->stream);
 
@@ -2102,6 +2111,7 @@ extern "C" int mpmc_hip_energy_begin(mpmc_hip_ctx *c) {
     }
     if (!issued && enqueue_direct(c)) return -1;
     c->staged_copies = false;
+    c->main_writes = false;
     clock_gettime(CLOCK_MONOTONIC, &ts1);
     c->host_enqueue_s += (ts1.tv_sec - ts0.tv_sec) + 1e-9 * (ts1.tv_nsec - ts0.tv_nsec);
     c->dirty_atoms.clear();
@@ -2341,6 +2351,8 @@ struct mpmc_hip_comm {
     int cap = 0;
     int nranks = 1, rank = 0;
     int pending = 0;               // doubles of the all-reduce in flight (0: none)
+    unsigned char *d_gather = nullptr, *h_gather = nullptr;  // mpmc_hip_gather_observables: [send | nranks records]
+    size_t gather_cap = 0;
 };
 
 struct Rccl {
@@ -2349,6 +2361,7 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t,
                               hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
@@ -2362,9 +2375,10 @@ static int load_rccl() {
     g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(h, "ncclGetUniqueId");
     g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(h, "ncclCommInitRank");
     g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(h, "ncclAllReduce");
+    g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(h, "ncclAllGather");
     g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
     g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
-    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy)
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.AllGather || !g_rccl.CommDestroy)
         return fail("MPMC_HIP: librccl lacks an expected symbol");
     g_rccl.h = h;
     return 0;
@@ -2402,9 +2416,14 @@ extern "C" int mpmc_hip_comm_create(mpmc_hip_comm **out, mpmc_hip_ctx *ctx, int 
         return rccl_fail("ncclCommInitRank", rc);
     }
     cm->cap = 64;
-    HIPCHK(hipStreamCreateWithFlags(&cm->stream, hipStreamNonBlocking));
-    HIPCHK(hipMalloc((void **)&cm->d_buf, cm->cap * sizeof(double)));
-    HIPCHK(hipHostMalloc((void **)&cm->h_buf, cm->cap * sizeof(double), hipHostMallocDefault));
+    // (not HIPCHK: a failure here must not leak the communicator the other ranks are now part of)
+    hipError_t e = hipStreamCreateWithFlags(&cm->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void **)&cm->d_buf, cm->cap * sizeof(double));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&cm->h_buf, cm->cap * sizeof(double), hipHostMallocDefault);
+    if (e != hipSuccess) {
+        mpmc_hip_comm_destroy(cm);
+        return fail("MPMC_HIP: comm_create: %s", hipGetErrorString(e));
+    }
     *out = cm;
     return 0;
 }
@@ -2448,6 +2467,32 @@ extern "C" int mpmc_hip_allreduce_observables(mpmc_hip_comm *cm, double *values,
     return mpmc_hip_allreduce_observables_end(cm, values);
 }
 
+// The reference's MPI_Gather of one byte record per walker (mc.c:431), as an all-gather: every rank ends up with
+// all records in rank order.  Blocking; staged through pinned memory on the communicator's own stream.
+extern "C" int mpmc_hip_gather_observables(mpmc_hip_comm *cm, const void *record, int bytes, void *records) {
+    if (!cm || !record || !records || bytes <= 0) return fail("MPMC_HIP: gather: bad arguments");
+    if (cm->pending) return fail("MPMC_HIP: gather: an all-reduce is in flight on this communicator");
+    HIPCHK(hipSetDevice(cm->device));
+    const size_t b = (size_t)bytes, need = b * (size_t)(cm->nranks + 1);
+    if (need > cm->gather_cap) {
+        if (cm->d_gather) HIPCHK(hipFree(cm->d_gather));
+        if (cm->h_gather) HIPCHK(hipHostFree(cm->h_gather));
+        cm->d_gather = cm->h_gather = nullptr;
+        cm->gather_cap = 0;
+        HIPCHK(hipMalloc((void **)&cm->d_gather, need));
+        HIPCHK(hipHostMalloc((void **)&cm->h_gather, need, hipHostMallocDefault));
+        cm->gather_cap = need;
+    }
+    memcpy(cm->h_gather, record, b);
+    HIPCHK(hipMemcpyAsync(cm->d_gather, cm->h_gather, b, hipMemcpyHostToDevice, cm->stream));
+    const ncclResult_t rc = g_rccl.AllGather(cm->d_gather, cm->d_gather + b, b, ncclChar, cm->nccl, cm->stream);
+    if (rc != ncclSuccess) return rccl_fail("ncclAllGather", rc);
+    HIPCHK(hipMemcpyAsync(cm->h_gather + b, cm->d_gather + b, b * cm->nranks, hipMemcpyDeviceToHost, cm->stream));
+    HIPCHK(hipStreamSynchronize(cm->stream));
+    memcpy(records, cm->h_gather + b, b * cm->nranks);
+    return 0;
+}
+
 extern "C" void mpmc_hip_comm_destroy(mpmc_hip_comm *cm) {
     if (!cm) return;
     hipSetDevice(cm->device);
@@ -2455,6 +2500,8 @@ extern "C" void mpmc_hip_comm_destroy(mpmc_hip_comm *cm) {
     if (cm->nccl && g_rccl.CommDestroy) g_rccl.CommDestroy(cm->nccl);
     if (cm->d_buf) hipFree(cm->d_buf);
     if (cm->h_buf) hipHostFree(cm->h_buf);
+    if (cm->d_gather) hipFree(cm->d_gather);
+    if (cm->h_gather) hipHostFree(cm->h_gather);
     if (cm->stream) hipStreamDestroy(cm->stream);
     delete cm;
 }

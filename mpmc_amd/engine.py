@@ -21,7 +21,7 @@ EXPORTS = [
     "mpmc_hip_download_amatrix", "mpmc_hip_download_ranking", "mpmc_hip_get_timings",
     "mpmc_hip_comm_unique_id", "mpmc_hip_comm_create", "mpmc_hip_comm_size", "mpmc_hip_comm_rank",
     "mpmc_hip_allreduce_observables", "mpmc_hip_allreduce_observables_begin", "mpmc_hip_allreduce_observables_end",
-    "mpmc_hip_comm_destroy",
+    "mpmc_hip_gather_observables", "mpmc_hip_comm_destroy",
 ]
 
 
@@ -144,6 +144,7 @@ def load():
     lib.mpmc_hip_allreduce_observables.argtypes = [vp, vp, C.c_int]
     lib.mpmc_hip_allreduce_observables_begin.argtypes = [vp, vp, C.c_int]
     lib.mpmc_hip_allreduce_observables_end.argtypes = [vp, vp]
+    lib.mpmc_hip_gather_observables.argtypes = [vp, vp, C.c_int, vp]
     lib.mpmc_hip_comm_size.argtypes = [vp]
     lib.mpmc_hip_comm_rank.argtypes = [vp]
     lib.mpmc_hip_comm_destroy.argtypes = [vp]

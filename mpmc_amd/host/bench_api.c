@@ -5,7 +5,6 @@
 #include <math.h>
 #include "mpmc_host.h"
 
-int hip_download_dipoles(system_t *system);
 
 /* apply keyword lines ("polar_max_iter 4\npolar_gs on\n...") to a system built from arrays */
 int host_apply_config(system_t *system, const char *text) {
@@ -31,14 +30,13 @@ int host_apply_config(system_t *system, const char *text) {
 }
 
 /* run `nsteps` more MC steps on an initialised chain; returns accepted count */
-void host_profile_report(void);
 int host_mc_steps(system_t *system, int nsteps) {
     int acc0 = system->nodestats->accept;
     if (system->step == 0 && system->avg_observables->counter == 0.0) {
         /* first call: initial energy + first checkpoint, as mc() does */
         system->observables->volume = system->pbc->volume;
         double e = energy(system);
-        if (system->hip_error || e != e) return -1;
+        if (energy_hip_failed(system) || e != e) return -1;
         checkpoint(system);
         system->avg_observables->counter = 1.0;
     }
@@ -47,7 +45,7 @@ int host_mc_steps(system_t *system, int nsteps) {
         const double initial_energy = system->observables->energy;
         make_move(system);
         const double final_energy = energy(system);
-        if (system->hip_error) return -1; /* device failure: stop, never count it as a reject */
+        if (energy_hip_failed(system)) return -1; /* device failure: stop, never count it as a reject */
         if (final_energy != final_energy || final_energy - final_energy != 0.0) {
             system->observables->energy = MAXVALUE;
             system->nodestats->boltzmann_factor = 0;
@@ -76,7 +74,7 @@ int host_mc_steps_multi(system_t **systems, int nwalkers, int nsteps) {
         if (system->step == 0 && system->avg_observables->counter == 0.0) {
             system->observables->volume = system->pbc->volume;
             double e = energy(system);
-            if (system->hip_error || e != e) return -1;
+            if (energy_hip_failed(system) || e != e) return -1;
             checkpoint(system);
             system->avg_observables->counter = 1.0;
         }
@@ -90,15 +88,15 @@ int host_mc_steps_multi(system_t **systems, int nwalkers, int nsteps) {
             ++system->step;
             initial[w] = system->observables->energy;
             make_move(system);
-            ok[w] = (energy_begin(system) == 0);
+            ok[w] = (energy_hip_begin(system) == 0);
         }
         int failed = 0;
         for (int w = 0; w < nwalkers; w++) failed |= !ok[w];
         for (int w = 0; w < nwalkers; w++) {
             system_t *system = systems[w];
             /* every evaluation in flight is collected, also after a failure, so that no context is left mid-call */
-            const double final_energy = ok[w] ? energy_end(system) : NAN;
-            failed |= system->hip_error;
+            const double final_energy = ok[w] ? energy_hip_end(system) : NAN;
+            failed |= energy_hip_failed(system);
             if (failed) continue;
             if (final_energy != final_energy || final_energy - final_energy != 0.0) {
                 system->observables->energy = MAXVALUE;
@@ -120,12 +118,11 @@ int host_mc_steps_multi(system_t **systems, int nwalkers, int nsteps) {
     return accepted;
 }
 
-void host_set_device(system_t *system, int device) { system->hip_device = device; }
+void host_set_device(system_t *system, int device) { energy_hip_set_device(system, device); }
 void host_enable_timing(system_t *system, int on) {
-    system->hip_timing = on;
-    memset(&system->hip_timings_sum, 0, sizeof(system->hip_timings_sum));
+    energy_hip_enable_timing(system, on);
 }
-void host_get_timings(system_t *system, mpmc_hip_timings *out) { *out = system->hip_timings_sum; }
+void host_get_timings(system_t *system, mpmc_hip_timings *out) { energy_hip_get_timings(system, out); }
 void host_get_observables(system_t *system, double out[8]) {
     const observables_t *o = system->observables;
     out[0] = o->energy;
@@ -144,7 +141,7 @@ void host_get_positions(system_t *system, double *pos) {
             for (int p = 0; p < 3; p++) pos[3 * i + p] = a->pos[p];
 }
 int host_get_dipoles(system_t *system, double *mu, double *ef_static, double *ef_induced) {
-    if (hip_download_dipoles(system)) return -1;
+    if (energy_hip_download_dipoles(system)) return -1;
     int i = 0;
     for (molecule_t *m = system->molecules; m; m = m->next)
         for (atom_t *a = m->atoms; a; a = a->next, i++)
@@ -173,12 +170,13 @@ void host_init_chain_no_energy(system_t *system) {
 }
 
 int host_set_option(system_t *system, const char *name, int value) {
-    if (!system->hip_ctx) return -1;
-    return mpmc_hip_set_option(system->hip_ctx, name, value);
+    if (!energy_hip_context(system)) return -1;
+    return mpmc_hip_set_option(energy_hip_context(system), name, value);
 }
 
 int host_natoms(system_t *system) { return countNatoms(system); }
-int host_device_error(system_t *system) { return system->hip_error; }
+int host_device_error(system_t *system) { return energy_hip_failed(system); }
+void host_profile_report(void) { energy_hip_profile_report(); }
 /* full flat copy of the current configuration (N may have changed under uvt) */
 void host_get_system(system_t *system, double *pos, double *charge, double *alpha, double *eps, double *sig,
                      double *mass, int *molecule, int *frozen) {

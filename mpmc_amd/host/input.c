@@ -446,14 +446,10 @@ system_t *system_from_arrays(int n, const double *pos, const double *charge, con
     return system;
 }
 
-void host_profile_report(void);
-void hip_free_shadow(system_t *system);
 void free_system(system_t *system) {
     if (!system) return;
-    host_profile_report();
-    walkers_finalize(system);
-    if (system->hip_ctx) mpmc_hip_destroy(system->hip_ctx);
-    hip_free_shadow(system);
+    energy_hip_profile_report();
+    energy_hip_cleanup(system); /* communicator, device context, host image */
     free(system->movable);
     free(system->movable_prev);
     molecule_t *m = system->molecules;

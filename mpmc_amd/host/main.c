@@ -17,13 +17,14 @@ int main(int argc, char **argv) {
         error("MAIN: error initializing simulation\n");
         return 1;
     }
-    if (argc > 2) system->hip_device = atoi(argv[2]);
-    snprintf(linebuf, MAXLINE, "MAIN: %d atoms, HIP energy engine on device %d\n", system->natoms, system->hip_device);
+    const int device = argc > 2 ? atoi(argv[2]) : 0;
+    energy_hip_set_device(system, device);
+    snprintf(linebuf, MAXLINE, "MAIN: %d atoms, HIP energy engine on device %d\n", system->natoms, device);
     output(linebuf);
     int rc = 0;
     if (system->ensemble == ENSEMBLE_TE) {
         const double e = energy(system);
-        if (system->hip_error) rc = -1;
+        if (energy_hip_failed(system)) rc = -1;
         const observables_t *o = system->observables;
         snprintf(linebuf, MAXLINE,
                  "OUTPUT: potential energy = %.5f K\nOUTPUT: electrostatic energy = %.5f K\n"

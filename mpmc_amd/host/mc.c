@@ -230,11 +230,9 @@ void make_move(system_t *system) {
                 com[p] = 0;
                 for (int q = 0; q < 3; q++) com[p] += system->pbc->basis[q][p] * rand[q];
             }
-            hip_note_list_changed(system);
+            energy_hip_note_list_changed(system);
             system->movable_valid = 0;
             molecule_t *ins = cp->molecule_backup;
-            ins->hip_ticket = 0; /* a new molecule: it does not own the slots of the one it was copied from */
-            ins->hip_slot = -1;
             for (atom_t *a = ins->atoms; a; a = a->next)
                 for (int p = 0; p < 3; p++) a->pos[p] += com[p] - ins->com[p];
             for (int p = 0; p < 3; p++) ins->com[p] = com[p];
@@ -251,7 +249,7 @@ void make_move(system_t *system) {
             break;
         }
         case MOVETYPE_REMOVE:
-            hip_note_list_changed(system);
+            energy_hip_note_list_changed(system);
             system->movable_valid = 0;
             /* remove 'altered' from the list */
             if (!cp->head)
@@ -264,7 +262,7 @@ void make_move(system_t *system) {
         default:
             translate(system, cp->molecule_altered, system->pbc, system->move_factor);
             rotate(system, cp->molecule_altered, system->pbc, system->rot_factor);
-            hip_note_touched(system, cp->molecule_altered);
+            energy_hip_note_moved(system, cp->molecule_altered, cp->molecule_altered);
     }
 }
 
@@ -274,7 +272,7 @@ void restore(system_t *system) {
     memcpy(system->observables, cp->observables, sizeof(observables_t));
     switch (cp->movetype) {
         case MOVETYPE_INSERT:
-            hip_note_list_changed(system);
+            energy_hip_note_list_changed(system);
             system->movable_valid = 0;
             /* take altered out of the list */
             if (!cp->head)
@@ -285,7 +283,7 @@ void restore(system_t *system) {
             cp->molecule_altered = NULL;
             break;
         case MOVETYPE_REMOVE:
-            hip_note_list_changed(system);
+            energy_hip_note_list_changed(system);
             system->movable_valid = 0;
             /* put backup back into the list */
             if (!cp->head)
@@ -303,7 +301,8 @@ void restore(system_t *system) {
                 else
                     cp->head->next = cp->molecule_backup;
                 cp->molecule_backup->next = cp->tail;
-                hip_note_touched(system, cp->molecule_backup); /* the device still holds the rejected coordinates */
+                /* the device still holds the rejected coordinates; the backup takes the altered node's place */
+                energy_hip_note_moved(system, cp->molecule_backup, cp->molecule_altered);
                 if (system->movable_valid) { /* the backup takes the altered molecule's place in the table too */
                     const int k = cp->altered_index;
                     system->movable[k] = cp->molecule_backup;
@@ -342,67 +341,22 @@ static void write_observables(FILE *fp, system_t *system, observables_t *o, doub
     fflush(fp);
 }
 
-static void update_averages(system_t *system) {
+/* one walker's record in the gather at corrtime (the reference packs observables_t + avg_nodestats_t, mc.c:417-428) */
+typedef struct {
+    observables_t observables;
+    double polarization_iterations;
+} walker_record_t;
+
+static void update_averages(system_t *system, const observables_t *o, double polarization_iterations) {
     avg_observables_t *a = system->avg_observables;
-    observables_t *o = system->observables;
     const double m = a->counter / (a->counter + 1.0), f = 1.0 / (a->counter + 1.0); /* running mean, average.c:213-229 */
     a->energy = m * a->energy + f * o->energy;
     a->energy_sq = m * a->energy_sq + f * o->energy * o->energy;
     a->coulombic_energy = m * a->coulombic_energy + f * o->coulombic_energy;
     a->rd_energy = m * a->rd_energy + f * o->rd_energy;
     a->polarization_energy = m * a->polarization_energy + f * o->polarization_energy;
-    a->polarization_iterations = m * a->polarization_iterations + f * system->nodestats->polarization_iterations;
+    a->polarization_iterations = m * a->polarization_iterations + f * polarization_iterations;
     a->counter += 1.0;
-}
-
-/* ---- walker pooling: the MPI_Gather of the reference (mc.c:417-432), over RCCL through the C ABI ---- */
-int walkers_unique_id(unsigned char id[128]) {
-    if (mpmc_hip_comm_unique_id(id)) {
-        error("MC: could not make a communicator id\n");
-        return -1;
-    }
-    return 0;
-}
-
-int walkers_init(system_t *system, int nranks, int rank, const unsigned char id[128]) {
-    if (nranks < 1 || rank < 0 || rank >= nranks) return -1;
-    system->walker_rank = rank;
-    system->walker_nranks = nranks;
-    if (nranks == 1 && !id) return 0; /* nothing to pool with (with an id a 1-rank communicator is made: same code path) */
-    if (!system->hip_ctx) {
-        error("MC: walkers_init needs the device context (call energy() first)\n");
-        return -1;
-    }
-    if (mpmc_hip_comm_create(&system->hip_comm, system->hip_ctx, nranks, rank, id)) {
-        char buf[2 * MAXLINE];
-        snprintf(buf, sizeof(buf), "MC: walkers_init: %s\n", mpmc_hip_last_error());
-        error(buf);
-        return -1;
-    }
-    return 0;
-}
-
-int walkers_pool_begin(system_t *system, const double *values, int count) {
-    if (count <= 0 || count > 64) return -1;
-    if (!system->hip_comm) { /* a single walker: the pooled sums are its own */
-        memcpy(system->walker_pool_buf, values, count * sizeof(double));
-        return 0;
-    }
-    return mpmc_hip_allreduce_observables_begin(system->hip_comm, values, count) ? -1 : 0;
-}
-
-int walkers_pool_end(system_t *system, double *values, int count) {
-    if (count <= 0 || count > 64) return -1;
-    if (!system->hip_comm) {
-        memcpy(values, system->walker_pool_buf, count * sizeof(double));
-        return 0;
-    }
-    return mpmc_hip_allreduce_observables_end(system->hip_comm, values) ? -1 : 0;
-}
-
-void walkers_finalize(system_t *system) {
-    if (system->hip_comm) mpmc_hip_comm_destroy(system->hip_comm);
-    system->hip_comm = NULL;
 }
 
 /* implements the Markov chain */
@@ -415,11 +369,18 @@ int mc(system_t *system) {
     /* get the initial energy of the system */
     system->step = 0;
     initial_energy = energy(system);
-    if (system->hip_error) return -1; /* device failure: not a property of the configuration */
+    if (energy_hip_failed(system)) return -1; /* device failure: not a property of the configuration */
+    /* one process per GPU started by a plain launcher: MPMC_HIP_RANK / MPMC_HIP_NRANKS / MPMC_HIP_ID_FILE name the
+     * walker (the reference's `rank`, `size`: main.c:45-52); the communicator lives on the device energy() chose */
+    const int size = getenv("MPMC_HIP_NRANKS") ? atoi(getenv("MPMC_HIP_NRANKS")) : 1;
+    const int rank = getenv("MPMC_HIP_RANK") ? atoi(getenv("MPMC_HIP_RANK")) : 0;
+    if (walkers_init_from_env(system) < 0) return -1;
+    walker_record_t snd, *rcv = calloc(size > 0 ? size : 1, sizeof(walker_record_t));
+    if (!rcv) return -1;
     /* be a bit forgiving of the initial state */
     if (!isfinite(initial_energy)) initial_energy = system->observables->energy = MAXVALUE;
 
-    if (system->energy_output[0] && !system->fp_energy) {
+    if (!rank && system->energy_output[0] && !system->fp_energy) {
         system->fp_energy = fopen(system->energy_output, "w");
         if (!system->fp_energy) {
             error("MC: could not open files\n");
@@ -428,7 +389,8 @@ int mc(system_t *system) {
         fprintf(system->fp_energy,
                 "#step #energy #coulombic #rd #polar #vdw #kinetic #kin_temp #N #spin_ratio #volume #core_temp\n");
     }
-    update_averages(system);
+    /* average in the initial values once (root only, as mc.c:276-279) */
+    if (!rank) update_averages(system, system->observables, system->nodestats->polarization_iterations);
     if (system->fp_energy) write_observables(system->fp_energy, system, system->observables, system->temperature);
 
     /* save the initial state */
@@ -442,8 +404,9 @@ int mc(system_t *system) {
         make_move(system);
         /* calculate the energy change */
         final_energy = energy(system);
-        if (system->hip_error) { /* a device / ABI failure is never turned into a rejected move */
+        if (energy_hip_failed(system)) { /* a device / ABI failure is never turned into a rejected move */
             error("MC: the device engine failed, stopping the chain\n");
+            free(rcv);
             return -1;
         }
         /* treat a bad contact as a reject */
@@ -469,11 +432,24 @@ int mc(system_t *system) {
 
         /* do this every correlation time */
         if (!(system->step % system->corrtime)) {
-            update_averages(system);
-            if (system->fp_energy)
-                write_observables(system->fp_energy, system, system->observables, system->temperature);
+            /* every walker's record to every rank (mc.c:431 MPI_Gather; here an all-gather over xGMI), then the
+             * head node averages walker by walker and writes one line per walker (mc.c:443-476) */
+            memset(&snd, 0, sizeof(snd));
+            snd.observables = *system->observables;
+            snd.polarization_iterations = system->nodestats->polarization_iterations;
+            if (walkers_gather(system, &snd, (int)sizeof(snd), rcv) < 0) {
+                free(rcv);
+                return -1;
+            }
+            if (!rank)
+                for (int j = 0; j < size; j++) {
+                    if (system->fp_energy)
+                        write_observables(system->fp_energy, system, &rcv[j].observables, system->temperature);
+                    update_averages(system, &rcv[j].observables, rcv[j].polarization_iterations);
+                }
         }
     }
+    free(rcv);
     snprintf(linebuf, MAXLINE, "MC: %d steps, acceptance rate %.4f, <E> = %.6f K\n", system->numsteps,
              system->nodestats->acceptance_rate, system->avg_observables->energy);
     output(linebuf);

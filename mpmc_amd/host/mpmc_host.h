@@ -16,7 +16,7 @@
 
 #include <stdio.h>
 
-#include "../../include/mpmc_hip.h"
+#include <mpmc_hip.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -51,11 +51,6 @@ typedef struct _molecule {
     double com[3], wrapped_com[3];
     atom_t *atoms;
     struct _molecule *next;
-    /* HIP engine residency: first device slot of the molecule's atoms and the ticket that proves the slots are
-     * still this molecule's (copied by copy_molecule(), so a restored backup keeps its place; cleared on the copy
-     * that make_move() inserts) */
-    int hip_slot;
-    unsigned long long hip_ticket;
 } molecule_t;
 
 typedef struct _pbc {
@@ -120,30 +115,12 @@ typedef struct _system {
     avg_observables_t *avg_observables;
     checkpoint_t *checkpoint;
     double last_volume;
-    /* device engine (opaque to callers) */
-    mpmc_hip_ctx *hip_ctx;
-    void *hip_shadow; /* host image of the device configuration (energy_hip.c) */
-    int hip_device, hip_uploaded_natoms, hip_dirty_all, hip_capacity;
-    /* Which molecules may differ from the device copy since the last energy(): mc.c notes every molecule it
-     * displaces or puts back (hip_note_touched); while hip_in_sync holds, energy() looks at those only instead
-     * of walking all lists.  Anything else that edits the lists clears hip_in_sync (hip_note_list_changed). */
-    int hip_in_sync, hip_ntouched;
-    /* Device / ABI failure of the last energy(): its own channel, NOT a Monte Carlo reject.  energy() still
-     * returns NAN (the double has no room for an error), but mc() and host_mc_steps() look here first and
-     * stop with -1; only a call that succeeded and produced a non-finite energy is a "bad contact". */
-    int hip_error;
     /* the movable (non-frozen) molecules in list order and each one's predecessor in the list, so that
      * checkpoint() need not walk the list twice per step; rebuilt after insertions / removals */
     struct _molecule **movable, **movable_prev;
     int nmovable, movable_cap, movable_valid;
-    struct _molecule *hip_touched[8];
-    /* walker pooling over xGMI (replaces the reference's MPI_Gather, src/mc/mc.c:417-432): one communicator per
-     * walker process, created by walkers_init() from a 128-byte id that rank 0 made and the launcher handed round */
-    mpmc_hip_comm *hip_comm;
-    int walker_rank, walker_nranks;
-    double walker_pool_buf[64]; /* a single walker's "pooled" sums between pool_begin and pool_end */
-    mpmc_hip_timings hip_timings_sum; /* accumulated over energy() calls since mc() started */
-    int hip_timing;
+    /* (no engine fields: energy_hip.c keeps device context, residency, failure flag, communicator and timings in a
+     * side table keyed by the system_t pointer -- exactly as it does inside the reference tree) */
     FILE *fp_energy;
 } system_t;
 
@@ -159,12 +136,9 @@ system_t *system_from_arrays(int n, const double *pos, const double *charge, con
                              const int *frozen, const double basis[9]);
 void free_system(system_t *system);
 
-/* energy (reference src/energy/energy.c) */
+/* energy (reference src/energy/energy.c; energy.c here is the dispatcher with the `hip` hook, energy_hip.c the
+ * binding itself -- see energy_hip.h, included at the end of this header) */
 double energy(system_t *system);
-void hip_note_touched(system_t *system, molecule_t *m);  /* m's atoms moved, or m took a backup's place */
-void hip_note_list_changed(system_t *system);           /* molecules inserted / removed / re-read */
-int energy_begin(system_t *system);  /* energy() in two halves, so that several walkers can share a process */
-double energy_end(system_t *system);
 int countNatoms(system_t *system);
 void update_com(molecule_t *molecules);
 
@@ -181,16 +155,6 @@ void free_molecule(system_t *system, molecule_t *molecule);
 void translate(system_t *system, molecule_t *molecule, pbc_t *pbc, double scale);
 void rotate(system_t *system, molecule_t *molecule, pbc_t *pbc, double scale);
 
-/* walker averaging (reference src/mc/mc.c:417-476: MPI_Gather + update_root_averages; here every rank gets the
- * pooled sums).  walkers_unique_id() on rank 0, the launcher distributes the id, walkers_init() on every rank
- * after its first energy() (the communicator lives on the engine's device); walkers_pool_begin()/_end() sum a
- * short vector over all walkers.  With one rank (or before walkers_init) pooling is the identity. */
-int walkers_unique_id(unsigned char id[128]);
-int walkers_init(system_t *system, int nranks, int rank, const unsigned char id[128]);
-int walkers_pool_begin(system_t *system, const double *values, int count);
-int walkers_pool_end(system_t *system, double *values, int count);
-void walkers_finalize(system_t *system);
-
 /* output */
 void output(const char *msg);
 void error(const char *msg);
@@ -199,4 +163,6 @@ int write_molecules(system_t *system, const char *filename);
 #ifdef __cplusplus
 }
 #endif
+
+#include "energy_hip.h" /* energy_hip(), the notes, the dipole download, walkers_*() */
 #endif

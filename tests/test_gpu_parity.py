@@ -993,8 +993,80 @@ def test_rccl_single_rank_allreduce():
     v = np.arange(8, dtype=np.float64)
     assert lib.mpmc_hip_allreduce_observables(comm, v.ctypes.data, 8) == 0, lib.mpmc_hip_last_error()
     assert np.array_equal(v, np.arange(8, dtype=np.float64))
+    # the MPI_Gather of mc.c:431 as an all-gather of byte records (one rank: its own record comes back)
+    rec = np.frombuffer(os.urandom(301), dtype=np.uint8).copy()
+    out = np.zeros(301, dtype=np.uint8)
+    assert lib.mpmc_hip_gather_observables(comm, rec.ctypes.data, 301, out.ctypes.data) == 0, lib.mpmc_hip_last_error()
+    assert np.array_equal(rec, out)
+    big = np.arange(70000, dtype=np.uint8)  # the buffers grow
+    outb = np.zeros_like(big)
+    assert lib.mpmc_hip_gather_observables(comm, big.ctypes.data, big.size, outb.ctypes.data) == 0
+    assert np.array_equal(big, outb)
     lib.mpmc_hip_comm_destroy(comm)
     eng.close()
+
+
+@pytest.mark.parametrize("flags", [dict(polar_max_iter=4), dict(polar_max_iter=4, polar_gs_ranked=1, polar_palmo=1, polar_wolf=1,
+                                                                polar_wolf_alpha=0.13, polar_gamma=1.03),
+                                   dict(polar_max_iter=0, polar_precision=1e-6)],
+                         ids=["jacobi", "production", "precision"])
+def test_side_stream_sees_main_stream_writes_that_bypass_the_move_list(flags):
+    """A big update (staged copy on the main stream), an insertion (apply_edits_kernel) or a restated sweep order,
+    FOLLOWED by a small update (which queues a MoveList entry) before the same energy(): the LJ / Ewald stream must
+    not just apply the small move for itself and run -- it has to wait for the main stream's other writes.  Every
+    term bitwise equal to a fresh context holding the same configuration (round-2 advisor finding)."""
+    s = synth.s_pol(1280)
+    n = len(s["charge"])
+    p = dict(temperature=77.0, polarization=1, polar_damp=2.1304, feynman_hibbs=1, feynman_hibbs_order=4, **flags)
+    terms = ("energy", "rd_energy", "coulombic_energy", "polarization_energy", "es_real", "es_recip")
+    rng = np.random.default_rng(5)
+
+    def fresh(system):
+        e = engine.Engine(len(system["charge"]) + 64)
+        e.load_system(system, p)
+        r = e.energy()
+        e.close()
+        return tuple(r[t] for t in terms)
+
+    # (1) 40 atoms (8 molecules: beyond the MoveList, staged through pinned memory), then 3 atoms... of one molecule: 5
+    e = engine.Engine(n + 64)
+    e.load_system(s, p)
+    e.energy()
+    for trial in range(3):
+        pos = s["pos"].copy()
+        first_big = 5 * int(rng.integers(0, n // 5 - 8))
+        pos[first_big:first_big + 40] += rng.normal(scale=0.3, size=(40, 3))
+        first_small = 5 * int(rng.integers(0, n // 5))
+        while first_big <= first_small < first_big + 40:
+            first_small = 5 * int(rng.integers(0, n // 5))
+        pos[first_small:first_small + 5] += rng.normal(scale=0.3, size=3)
+        e.update_atoms(first_big, pos[first_big:first_big + 40])
+        e.update_atoms(first_small, pos[first_small:first_small + 5])
+        r = e.energy()
+        assert tuple(r[t] for t in terms) == fresh(dict(s, pos=pos)), ("staged copy then small move", trial)
+        e.update_atoms(first_big, s["pos"][first_big:first_big + 40])
+        e.update_atoms(first_small, s["pos"][first_small:first_small + 5])
+        e.energy()
+    e.close()
+    # (2) an insertion, then a small displacement of another molecule, then energy()
+    e = engine.Engine(n + 64)
+    e.load_system(s, p)
+    e.energy()
+    sl = slice(35, 40)
+    newpos = s["pos"][sl] + np.array([1.7, 1.9, -1.6])
+    first = e.insert_molecule(newpos, s["charge"][sl], s["alpha"][sl], s["epsilon"][sl], s["sigma"][sl], s["mass"][sl])
+    assert first == n
+    moved = s["pos"][700:705] + np.array([0.2, -0.1, 0.15])
+    e.update_atoms(700, moved)
+    if flags.get("polar_gs_ranked"):
+        e.set_sweep_order(np.where(np.concatenate([s["alpha"], s["alpha"][sl]]) != 0.0)[0])
+    r = e.energy()
+    s2 = {k: (np.concatenate([v, v[sl]]) if k not in ("basis", "pos", "molecule") else v) for k, v in s.items()}
+    s2["pos"] = np.concatenate([s["pos"], newpos])
+    s2["pos"][700:705] = moved
+    s2["molecule"] = np.concatenate([s["molecule"], np.full(5, s["molecule"].max() + 1, dtype=np.int32)])
+    assert tuple(r[t] for t in terms) == fresh(s2), "insertion then small move"
+    e.close()
 
 
 # ---------------------------------------------------------------------------------------------
