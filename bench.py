@@ -74,6 +74,12 @@ def parse_args(argv=None):
     ap.add_argument("--full-rebuild", action="store_true", help="A/B: rebuild every cached unit from scratch every step")
     ap.add_argument("--expanded-matrix", action="store_true",
                     help="A/B: sweep over the expanded 3N x 3N matrix (72 B per pair) instead of pair coefficients (16 B)")
+    ap.add_argument("--deadline", type=float, default=900.0,
+                    help="seconds the self-started ranks of --gpus N get, rank 0 included; after that exactly the PIDs "
+                         "started here are killed and the exit code is non-zero")
+    ap.add_argument("--launch-fault", default="",
+                    help="test hook of --launch-check: 'exit:R' makes rank R exit with code 3 before the rendezvous, "
+                         "'hang:R' makes it sleep past any deadline")
     ap.add_argument("--launch-check", action="store_true",
                     help="exercise the rank launcher and the seed/pooling bookkeeping WITHOUT a GPU (gloo, no energy is "
                          "evaluated, value is null): what the CPU tests run")
@@ -113,27 +119,57 @@ def launch_ranks(args):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    procs = []
+    import tempfile
+
+    procs, errs = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MPMC_BENCH_SPAWNED="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        errs.append(tempfile.TemporaryFile())
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else None))
-    out, _ = procs[0].communicate()
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=errs[-1]))
+    # ONE deadline for all ranks, rank 0 included: a rank stuck in a collective (ncclCommInitRank on a node where one
+    # peer died, a rendezvous nobody joins) must end as a non-zero exit with a message, not as a run the caller's own
+    # time limit kills with nothing written.
+    deadline = time.time() + args.deadline
+    out, timed_out = b"", []
+    try:
+        out, _ = procs[0].communicate(timeout=max(1.0, deadline - time.time()))
+    except subprocess.TimeoutExpired:
+        timed_out.append(0)
     rcs = [procs[0].returncode]
-    deadline = time.time() + 120.0
-    for p in procs[1:]:
+    # once rank 0 is done (or out of time) the others get a short grace period: they leave the last barrier together
+    grace = time.time() + (20.0 if not timed_out else 0.0)
+    for r, p in enumerate(procs[1:], start=1):
         try:
-            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
+            rcs.append(p.wait(timeout=max(0.5, min(deadline, grace) - time.time())))
         except subprocess.TimeoutExpired:
+            timed_out.append(r)
+            rcs.append(None)
+    for r, p in enumerate(procs):
+        if p.poll() is None:
             p.kill()  # exactly the PIDs started above
-            rcs.append(-9)
-    text = out.decode() if out else ""
+            p.wait()
+            if r == 0:
+                try:
+                    out = p.stdout.read() or b""
+                except Exception:  # noqa: BLE001
+                    out = b""
+            rcs[r] = -9
+    text = out.decode(errors="replace") if out else ""
     sys.stdout.write(text)
     sys.stdout.flush()
-    if any(rc != 0 for rc in rcs):
-        sys.stderr.write("bench.py: rank exit codes %s\n" % rcs)
+    failed = timed_out or any(rc != 0 for rc in rcs)
+    for r, f in enumerate(errs):
+        f.seek(0)
+        tail = f.read().decode(errors="replace").splitlines()[-(12 if failed else 3):]
+        f.close()
+        if tail and (failed or r == 0):
+            sys.stderr.write("".join("[rank %d] %s\n" % (r, ln) for ln in tail))
+    if failed:
+        sys.stderr.write("bench.py: rank exit codes %s%s\n" % (rcs, ("; ranks %s were still running at the %.0f s deadline "
+                         "and were killed" % (timed_out, args.deadline)) if timed_out else ""))
         return 1
     lines = [ln for ln in text.splitlines() if ln.startswith("{")]
     if len(lines) != 1 or json.loads(lines[0]).get("n_gpus") != n:
@@ -273,8 +309,18 @@ def launch_check(args, rank, world):
     from mpmc_amd import host, synth
     from mpmc_amd.walkers import TorchReducer, WalkerAverages, walker_seed
 
+    if args.launch_fault:
+        kind, _, who = args.launch_fault.partition(":")
+        if int(who or -1) == rank:
+            if kind == "exit":
+                sys.stderr.write("launch-check: rank %d exits on request\n" % rank)
+                sys.exit(3)
+            if kind == "hang":
+                time.sleep(3600.0)
     if world > 1:
-        dist.init_process_group(backend="gloo")
+        import datetime
+
+        dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=min(60.0, args.deadline)))
     seed = walker_seed(args.seed, rank)
     h = host.HostSystem(synth.s_pol(10), synth.FLAGS_POL_JACOBI, seed=seed)
     avg = WalkerAverages(reducer=TorchReducer(dist) if world > 1 else None)
@@ -357,19 +403,27 @@ def main():
         # Every rank tries the C ABI's communicator; they then agree (one all-reduce of the launcher's group) on whether
         # ALL of them have it.  If any could not (librccl missing, an init error), all fall back together to the
         # launcher's own all-reduce and the line says so -- a labelled number instead of a crashed scaling run.
+        # ncclCommInitRank is itself a collective: a rank that fails BEFORE it (librccl not loadable, no context)
+        # would leave the others blocked inside it.  So first every rank proves locally that it can enter -- making an
+        # id of its own loads librccl and runs it once -- and the ranks agree (MIN over the launcher's group); only then
+        # do all of them call walkers_init with rank 0's id.
         err = ""
+        my_id = None
         try:
-            ids = [host.walkers_unique_id() if rank == 0 else None]
+            my_id = host.walkers_unique_id()
         except Exception as e:  # noqa: BLE001 -- reported in the line
-            ids, err = [None], repr(e)
-        dist.broadcast_object_list(ids, src=0)
-        if ids[0] is not None and not err:
+            err = repr(e)
+        pre = torch.tensor([0.0 if err else 1.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(pre, op=dist.ReduceOp.MIN)
+        if float(pre.item()) > 0.5:
+            ids = [my_id if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
             try:
                 chain.walkers_init(world, rank, ids[0])
             except Exception as e:  # noqa: BLE001
                 err = repr(e)
         else:
-            err = err or "rank 0 could not make the RCCL id"
+            err = err or "another rank cannot load / run librccl"
         okt = torch.tensor([0.0 if err else 1.0], dtype=torch.float64, device=dev)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         if float(okt.item()) > 0.5:
@@ -436,6 +490,7 @@ def main():
     avg.summary()  # completes the last (asynchronous) walker all-reduce inside the timed region
     sync()
     elapsed = time.perf_counter() - t0
+    elapsed_own = elapsed
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -472,6 +527,20 @@ def main():
     torch.cuda.synchronize(dev)
     full_rebuild_rate = nfr / (time.perf_counter() - tf0)
 
+    # engine counters that would silently change what the headline measures (cumulative over this rank's whole run)
+    ctr = chain.timings()
+    rank_rec = {"rank": rank, "device": local_rank, "steps_per_s": W * args.steps / elapsed_own, "rccl_ok": rccl_ranks == world,
+                "own_mean_energy": avg.own_mean_energy(), "resident_fallbacks": int(ctr["resident_fallbacks"]),
+                "spec_rank_redos": int(ctr["spec_rank_redos"]), "resident_calls": int(ctr["resident_calls"])}
+    ranks = [rank_rec]
+    if dist is not None and world > 1:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, rank_rec)
+    # the preset_seeds trap (mersenne.cpp:13-14: every rank the same seed): walkers that are copies of each other would
+    # scale "perfectly" and average nothing.  Two ranks with the same mean energy over the run = the run is void.
+    means = [r["own_mean_energy"] for r in ranks]
+    identical = world > 1 and len(set(means)) < len(means)
+
     if rank == 0:
         value = world * W * args.steps / elapsed
         sweep_raw_ms = acc["sweep_ms"] / max(1, acc["sweep_count"])
@@ -487,8 +556,11 @@ def main():
         nblk = (n_pol + 63) // 64
         if gs:
             # gs_chain_kernel (the persistent lower-triangle launch of one exact Gauss-Seidel sweep): the {c3, c5}
-            # coefficients of every tile (t, s <= t-2) (16 B per pair), the expanded sub-diagonal tiles (t, t-1)
-            # (48 B per pair), the cached inverse of every diagonal block (32 x 9 x 64 doubles) and the vectors
+            # coefficients of every tile (t, s <= t-2) (16 B per pair), the sub-diagonal tiles (t, t-1) as expanded
+            # tensors (48 B per pair), the cached inverse of every diagonal block (32 x 9 x 64 doubles) and the vectors.
+            # (Round 2's accounting, kept so that the fraction stays comparable: round 3's kernel reads MORE than this --
+            # the cached matrices P_t, Q_t at 72 B per pair of the tiles (t, t-1), (t, t-2) -- by design, to shorten the
+            # chain; the PMC traffic in profiles/ shows what it really moves.)
             sweep_bytes = (max(nblk - 1, 0) * max(nblk - 2, 0) / 2) * 4096 * 16 + max(nblk - 1, 0) * 4096 * 48 \
                 + nblk * 18432 * 8 + 6 * m3 * 8
             kernel_name = "gs_chain_kernel"
@@ -540,6 +612,12 @@ def main():
             valu["static_field_kernel"] = dict(pairs_per_s=2 * npair / field_s, ms_full_pass=field_s * 1e3,
                                                est_flop_per_pair=15.5 + 0.03 * 71,
                                                est_frac_fp64_valu_peak=2 * npair * (15.5 + 0.03 * 71) / field_s / FP64_VALU_PEAK)
+        # what binds the dominant kernel: its coefficient set is re-read by every sweep; below the 256 MB Infinity Cache
+        # those re-reads can be served on-die, so the 8 TB/s HBM figure is the price list, not a proven roof, at that size
+        # (the same kernel at 16 384 atoms, 773 MB of coefficients, is the beyond-cache figure: DESIGN.md section 5)
+        bound_label = "hbm" if sweep_bytes > 256e6 else "hbm (set fits Infinity Cache)"
+        if gs:
+            bound_label = "hbm (latency chain: see DESIGN.md section 3)"
         out = {
             "metric": "MC steps/sec (polarizable, 4096 atoms)",
             "value": value,
@@ -563,7 +641,13 @@ def main():
                        "collective": collective,
                        "rccl_ranks": rccl_ranks},
             "full_rebuild_steps_per_s": full_rebuild_rate,
-            "roofline": {"kernel": kernel_name + " (Thole field / dipole sweep)", "bound": "hbm",
+            # a dedicated box shows 0 / 0: a resident (one-launch) solve that lost a hand-off is repeated launch by launch
+            # and the context stays on that path; a mis-speculated ranked walk is repeated with the host sorting
+            "resident_fallbacks": sum(r["resident_fallbacks"] for r in ranks),
+            "spec_rank_redos": sum(r["spec_rank_redos"] for r in ranks),
+            "resident_calls": sum(r["resident_calls"] for r in ranks),
+            "ranks": ranks,
+            "roofline": {"kernel": kernel_name + " (Thole field / dipole sweep)", "bound": bound_label,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": sweep_raw_ms, "launches": acc["sweep_count"],
@@ -593,11 +677,16 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, all_cores=bool(args.cpu_all_cores))
         print(json.dumps(out))
+    if identical:
+        sys.stderr.write("bench.py: walkers with IDENTICAL averages %s -- the ranks ran the same chain (seed + rank not "
+                         "applied?): the run is void\n" % means)
     for ch in chains:
         ch.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if identical:
+        sys.exit(4)
 
 
 if __name__ == "__main__":

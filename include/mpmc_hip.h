@@ -141,8 +141,8 @@ void mpmc_hip_destroy(mpmc_hip_ctx *ctx);
  *   "speculative_ranking" (default 1): polar_gs_ranked calls are enqueued for the ranked walk of the previous call
  *                          and checked on the device (repeated with the host sorting when the metric changed);
  *                          0 = the host sorts the ranking metric in every call;
- *   "fuse_tensor"         (default 1): Gauss-Seidel chain data after a move: the expanded sub-diagonal tiles ride in a
- *                          second z-slice of the block-inverse launch (0 = gs_neighbor_tensor_kernel on its own; A/B);
+ *   "fuse_tensor"         accepted and ignored (round 2's A/B switch for the expanded sub-diagonal tiles, which the chain
+ *                          kernel no longer uses: it holds P_t = M_t D T(t,t-1), built in the block-inverse launch);
  *   "rank_view_side"      (default 1): polar_gs_ranked calls in which the host sorts the metric (after a grand-canonical
  *                          edit, or when the speculated walk was wrong): the ranked view is (re)built on the side
  *                          stream beside the first sweep instead of on the main stream behind it (0 = main; A/B);

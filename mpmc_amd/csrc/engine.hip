@@ -131,7 +131,8 @@ struct SweepView {
     unsigned *gsflags = nullptr; // [8] gs_chain_kernel: ticket counter, sticky error word, breadcrumbs
     // Gauss-Seidel chain (kernels_gs_chain.h): cached inverses of the diagonal blocks and expanded sub-diagonal tiles
     double *Minv = nullptr;      // [cap/64][kMinvDoubles]
-    double2 *Tnb = nullptr;      // [cap/64][kTnbDouble2]
+    double *Pnb = nullptr;       // [cap/64][kPnbDoubles]: P_t = M_t D T(t,t-1)
+    double *Qnb = nullptr;       // [cap/64][kPnbDoubles]: Q_t = M_t D T(t,t-2)
     unsigned long long C_epoch = 0;   // bumped by every full build of C
     unsigned long long M_epoch = 0;   // C_epoch the chain data were last fully built under (0: never)
     unsigned long long M_call = 0;    // energy() call that last maintained them
@@ -235,6 +236,7 @@ struct mpmc_hip_ctx {
     unsigned long long resident_calls = 0, resident_fallbacks = 0;
     int opt_gs_ablate = 0;                 // timing-only ablations of the chain kernel (wrong results; tools/gs_ablate.py)
     int opt_gs_stamps = 0;                 // diagnostic: time stamps inside the chain kernel (printed by the sweep)
+    int gs_qoff = 0;                       // offset (doubles) of the q_t hand-off buffer inside a view's mupub
     unsigned long long *d_stamps = nullptr;
     int gs_sweeps_this_call = 0;
     int opt_pair_coef = 1;  // Jacobi/Palmo sweeps on pair coefficients (0: on the expanded A matrix)
@@ -552,7 +554,7 @@ extern "C" int mpmc_hip_set_option(mpmc_hip_ctx *c, const char *name, int value)
     else if (!strcmp(name, "gs_fold_upper"))
         c->opt_gs_fold_upper = value;  // 0: pair_upper_finish_kernel as a launch of its own in front of every chain launch
     else if (!strcmp(name, "fuse_tensor"))
-        c->opt_fuse_tensor = value;  // 0: gs_neighbor_tensor_kernel as a launch of its own (A/B; same bits)
+        c->opt_fuse_tensor = value;  // (round 2's A/B switch; accepted and ignored: the chain no longer uses tensor tiles)
     else if (!strcmp(name, "rank_late"))
         c->opt_rank_late = value;  // 0: in front of the main stream's view set-up (A/B; same results)
     else if (!strcmp(name, "fuse_field"))
@@ -660,7 +662,8 @@ extern "C" int mpmc_hip_create(mpmc_hip_ctx **out, int device, int max_atoms) {
         DALLOC(v.mu0, 3 * np, double);
         DALLOC(v.mu1, 3 * np, double);
         DALLOC(v.munew, 3 * np, double);
-        DALLOC(v.mupub, 3 * np + 192, double);  // (+ one spare block: target of the chain kernel's rehearsal stores)
+        DALLOC(v.mupub, 2 * (3 * np + 192), double);  // mu_t of a sweep, then (offset gs_qoff) the auxiliary q_t; a spare block each
+        c->gs_qoff = (int)(3 * np + 192);
         DALLOC(v.y, 3 * np, double);
         DALLOC(v.efind, 3 * np, double);
         DALLOC(v.efchg, 3 * np, double);
@@ -728,7 +731,7 @@ extern "C" void mpmc_hip_destroy(mpmc_hip_ctx *c) {
     for (void *p : dptrs)
         if (p) hipFree(p);
     for (SweepView &v : c->view) {
-        void *vp[] = {v.resP, v.respub, v.Srow, v.Minv, v.Tnb, v.mupub, v.gsflags, v.d_idx, v.d_slot, v.px, v.py, v.pz, v.palpha, v.pflags, v.A,    v.C, v.energy_part, v.es,
+        void *vp[] = {v.resP, v.respub, v.Srow, v.Minv, v.Pnb, v.Qnb, v.mupub, v.gsflags, v.d_idx, v.d_slot, v.px, v.py, v.pz, v.palpha, v.pflags, v.A,    v.C, v.energy_part, v.es,
                       v.mu0,   v.mu1, v.munew, v.y, v.efind, v.efchg, v.rrms};
         for (void *p : vp)
             if (p) hipFree(p);
@@ -1416,13 +1419,14 @@ static int ensure_view_coef(mpmc_hip_ctx *c, SweepView &v, int nt, hipStream_t s
     return 0;
 }
 
-// cached block inverses + expanded sub-diagonal tiles of the Gauss-Seidel chain, sized for the view's capacity
+// cached block inverses M_t + neighbour matrices P_t = M_t D T(t,t-1) of the Gauss-Seidel chain, sized for the view's capacity
 static int ensure_view_chain(mpmc_hip_ctx *c, SweepView &v, hipStream_t st) {
     (void)c;
-    if (v.Minv && v.Tnb) return 0;
+    if (v.Minv && v.Pnb && v.Qnb) return 0;
     const size_t nbcap = (size_t)(v.cap + 63) / 64;
     HIPCHK(hipMalloc((void **)&v.Minv, nbcap * kMinvDoubles * sizeof(double)));
-    HIPCHK(hipMalloc((void **)&v.Tnb, nbcap * kTnbDouble2 * sizeof(double2)));
+    HIPCHK(hipMalloc((void **)&v.Pnb, nbcap * kPnbDoubles * sizeof(double)));
+    HIPCHK(hipMalloc((void **)&v.Qnb, nbcap * kPnbDoubles * sizeof(double)));
     // the folded inverse has 32 padding lanes per block that no build writes: they must read as zero
     HIPCHK(hipMemsetAsync(v.Minv, 0, nbcap * kMinvDoubles * sizeof(double), st));
     v.M_epoch = 0;

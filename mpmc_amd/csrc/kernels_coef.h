@@ -587,13 +587,15 @@ __global__ __launch_bounds__(64 * kCoefWaves) void pair_upper_kernel(const doubl
                                                                        const double *__restrict__ mu, DevBox bx,
                                                                        double *__restrict__ Srow, int rev, int arm_nb,
                                                                        double *__restrict__ mu_new,
-                                                                       unsigned *__restrict__ gsflags) {
+                                                                       unsigned *__restrict__ gsflags, int arm_qoff) {
     // (arm_nb > 0: the chain kernel behind this launch adds up the row sums itself -- no pair_upper_finish_kernel -- so the
     //  hand-off buffer is armed here: workgroup b < arm_nb fills block b's 192 words with the sentinel, workgroup 0 zeroes
     //  the ticket counter; the error word, gsflags[1], is sticky for the whole energy() call and is NOT touched)
     if (arm_nb > 0) {
-        if ((int)blockIdx.x < arm_nb && threadIdx.x < 192)
+        if ((int)blockIdx.x < arm_nb && threadIdx.x < 192) {
             mu_new[192 * blockIdx.x + threadIdx.x] = __longlong_as_double(0x7ff8dead7ff8deadll);
+            mu_new[arm_qoff + 192 * blockIdx.x + threadIdx.x] = __longlong_as_double(0x7ff8dead7ff8deadll);  // q_t (aux workgroups)
+        }
         if (blockIdx.x == 0 && threadIdx.x == 0) gsflags[0] = 0u;
     }
     int ti, tj;
@@ -651,14 +653,17 @@ __global__ __launch_bounds__(64 * kCoefWaves) void pair_upper_kernel(const doubl
 __global__ __launch_bounds__(64 * kCoefFinishGroups) void pair_upper_finish_kernel(int nt, const double *__restrict__ Srow,
                                                                                     double *__restrict__ yout, int arm,
                                                                                     double *__restrict__ mu_new,
-                                                                                    unsigned *__restrict__ gsflags) {
+                                                                                    unsigned *__restrict__ gsflags, int arm_qoff) {
     const int t = blockIdx.x;
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int i = 64 * t + lane;
     if (arm) {  // this block's share of the hand-off buffer (192 doubles) and the ticket counter; the error word
                 // (gsflags[1]) is sticky for the whole energy() call and is NOT touched here
         const double sentinel = __longlong_as_double(0x7ff8dead7ff8deadll);
-        if (threadIdx.x < 192) mu_new[192 * t + threadIdx.x] = sentinel;
+        if (threadIdx.x < 192) {
+            mu_new[192 * t + threadIdx.x] = sentinel;
+            mu_new[arm_qoff + 192 * t + threadIdx.x] = sentinel;  // q_t (the chain's auxiliary workgroups)
+        }
         if (t == 0 && threadIdx.x == 0) gsflags[0] = 0u;
     }
     __shared__ double part[kCoefFinishGroups][3][64];

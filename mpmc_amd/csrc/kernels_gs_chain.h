@@ -10,20 +10,39 @@
 // coefficients and rebuilt only for the block(s) that hold a moved atom (gs_block_inverse_kernel: forward
 // substitution on the identity, one wave per column).  The sweep's critical path per block is then
 //     hand-off of mu_{t-1}  ->  T(t,t-1) mu_{t-1}  ->  M_t v_t       (two 64 x 64 block products)
-// instead of a 63-step dependent chain (8.5 us per block in round 1, ~2 us here).  The result is algebraically
-// the reference's; it differs from the literal substitution by rounding only (1e-13 relative, tests hold 1e-10).
+// instead of a 63-step dependent chain (8.5 us per block in round 1, ~2.1 us in round 2).  Round 3 takes one of the
+// two products and two of the three barriers off that path with a second cached matrix,
+//     P_t = M_t D T(t,t-1)      (192 x 192, dense),        mu_t = w_t - P_t mu_{t-1},
+//     w_t = M_t D (e + yU - sum_{s<=t-2} T(t,s) mu_s),
+// where w_t needs nothing newer than mu_{t-2} and is complete one block-time before mu_{t-1} arrives: what is left
+// between two publications is hand-off -> ONE product -> one cross-wave sum -> publication.  P_t's columns solve
+// (I + D L) x = D T(t,t-1)[:, column] -- the same forward substitution as M_t's, with another right-hand side -- so
+// they are built by the same kernel (gs_block_inverse_kernel, z-slice 1) and cached / invalidated like M_t (P_t depends
+// on blocks t and t-1).  Measured (profiles/r03_gs/): with P_t alone the sweep got SLOWER (98 vs 91 us at 39 blocks):
+// the chain's critical section did shrink to 1.6 us per block (63 us per sweep with the source loop ablated), but w_t
+// hangs on mu_{t-2} through stages that cost as much as the ones removed -- hand-off 1.07 + tile product 0.84 + sums
+// 0.4 + M_t product 1.08 + the final stage 1.1 = 4.5 us per TWO blocks.  So mu_{t-2} is taken off that path the same
+// way: Q_t = M_t D T(t,t-2) is cached as well, and because one CU's registers hold one such matrix (288 KB of its
+// 512 KB) the product Q_t mu_{t-2} is made by a second, AUXILIARY workgroup of block t on another CU, which does
+// nothing else: it publishes q_t = Q_t mu_{t-2} one hand-off before mu_{t-1} arrives, and the main workgroup forms
+//     mu_t = (w''_t - q_t) - P_t mu_{t-1},      w''_t = M_t D (e + yU - sum_{s<=t-3} T(t,s) mu_s),
+// with w''_t hanging on mu_{t-3} (two block-times of slack for its ~3.3 us of stages).
+// The result is algebraically the reference's; it differs from the literal substitution by rounding only (1e-13
+// relative, tests hold 1e-10).
 //
-// Work decomposition: ONE workgroup per 64-atom block, 8 waves, no separate spine / owner roles.  A workgroup
-// draws its block index t from a ticket counter when it STARTS, so it only ever waits for blocks whose
-// workgroups are already running or done: no co-residency assumption, no deadlock under any dispatch order or
-// oversubscription (several walkers on one GPU).  Workgroup t
-//   1. stages M_t in LDS (147 KB) and the neighbour tensor tile T(t,t-1) in registers (expanded, 6 doubles per
-//      pair, from gs_neighbor_tensor_kernel) -- nothing on the critical path touches HBM;
-//   2. for s = 0 .. t-2, as mu_s is published: acc += T(t,s) mu_s from the 16-B pair coefficients, geometry
+// Work decomposition: a MAIN workgroup per 64-atom block (8 waves) plus, for t >= 2, the auxiliary one.  A workgroup
+// draws its role from a ticket counter when it STARTS -- tickets 0, 1: main(0), main(1); then aux(t), main(t) for
+// t = 2, 3, ... -- so it only ever waits for data of workgroups with a smaller ticket, which are already running or
+// done (aux(t) waits for main(t-2), main(t) for main(s < t) and aux(t)): no co-residency assumption, no deadlock under
+// any dispatch order or oversubscription (several walkers on one GPU).  Main workgroup t
+//   1. stages M_t in LDS (147 KB) and P_t in registers (288 KB = 72 doubles per lane of the 128 a lane has at two
+//      waves per SIMD) -- nothing on the critical path touches HBM;
+//   2. for s = 0 .. t-3, as mu_s is published: acc += T(t,s) mu_s from the 16-B pair coefficients, geometry
 //      rebuilt in registers as in pair_sweep_kernel (lane = source atom, the target sums rotate across the
 //      lanes; forward and backward passes alternate so the sums end where they started); coefficients of the
 //      next tile are in flight while the current one is multiplied;
-//   3. on mu_{t-1}: neighbour product from registers, v_t, M_t v_t from LDS, publishes mu_t.
+//   3. on mu_{t-3} (the last of those sources): v = D (e + yU - acc), w''_t = M_t v from LDS;
+//   4. on mu_{t-1}: P_t mu_{t-1} from registers, cross-wave sum, publishes mu_t = (w''_t - q_t) - that.
 // Hand-offs are data-is-the-flag (Guideline 16, R2 with the value as its own tag): mu_new is pre-filled with
 // a sentinel NaN pattern, the producer writes every double with one agent-scope (sc1, write-through) 8-byte
 // store, consumers poll their own element with agent-scope loads.  Every spin is bounded; a give-up sets a
@@ -61,16 +80,23 @@ __device__ __forceinline__ int minv_index(int row, int col, int e) {  // row > c
     return ((w * 18 + (f >> 1)) * 64 + l) * 2 + (f & 1);
 }
 
-// ---- expanded neighbour tile T(t, t-1): target atom i of block t, source atom j of block t-1
-//   Tnb[((t * 64 + j) * 3 + h) * 64 + i] = double2 {xx,xy} (h = 0), {xz,yy} (h = 1), {yz,zz} (h = 2)
-constexpr int kTnbDouble2 = 64 * 3 * 64;  // per block (196 608 B)
+// ---- cached neighbour matrix P_t = M_t D T(t, t-1): target atom i (component p) of block t, source atom j
+// (component q) of block t-1, element e = 3 p + q.  Wave w of the chain kernel multiplies the sources j = w + 8 k
+// (k = 0..7); two of them (k = 2 m, 2 m + 1) share a 16-byte word so that the 72 doubles per lane arrive as 36 loads:
+//   Pnb[t * 36864 + ((((j & 7) * 4 + (j >> 4)) * 9 + e) * 64 + i) * 2 + ((j >> 3) & 1)]
+constexpr int kPnbDoubles = 64 * 9 * 64;  // per block (294 912 B)
+__device__ __forceinline__ int pnb_index(int i, int j, int e) {
+    return ((((j & 7) * 4 + (j >> 4)) * 9 + e) * 64 + i) * 2 + ((j >> 3) & 1);
+}
 
 struct GsChain {
     const double2 *C;  // pair-coefficient tiles of the view (kernels_coef.h)
     int ntld, nb;
     const double *px, *py, *pz, *alpha, *es;
     const double *Minv;
-    const double2 *Tnb;
+    const double *Pnb;   // P_t = M_t D T(t,t-1)
+    const double *Qnb;   // Q_t = M_t D T(t,t-2), same layout
+    double *q_pub;       // hand-off buffer of the auxiliary workgroups: q_t = Q_t mu_{t-2}, laid out and armed like mu_new
     double *y;         // in: upper-triangle part (pair_upper_finish_kernel); out: E_induced at update time
     double *mu_new;    // out, PLANAR per block: mu_new[192 t + 64 q + i] = component q of atom i of block t (so that a
                        // block is published with 16-byte stores and polled with coalesced loads); pre-filled with
@@ -175,49 +201,11 @@ __device__ __forceinline__ double wave_rotate_up(double v) {
     return __hiloint2double(hi, lo);
 }
 
-// ---------------------------------------------------------------------------------------------
-// Expanded tensors of the sub-diagonal tiles (t, t-1), t = blk[b] (or every t >= 1 with nsel = 0).
-// grid = nsel or nb - 1; block = 256.  A tile is a pure function of its two blocks' coordinates.
-// ---------------------------------------------------------------------------------------------
 constexpr int kMaxBlockList = 48;
 struct BlockList {
     int n;
     int blk[kMaxBlockList];
 };
-
-// (rows: the tile's source atoms j = jw + 4 kk, kk = k0 .. k0 + nk - 1, jw = wave of a 256-thread workgroup)
-template <int ORTHO>
-__device__ __forceinline__ void gs_neighbor_tensor_body(const double2 *__restrict__ C, int ntld, const double *__restrict__ px,
-                                                        const double *__restrict__ py, const double *__restrict__ pz,
-                                                        const DevBox &bx, int t, int k0, int nk, double2 *__restrict__ Tnb) {
-    if (t < 1) return;
-    const double2 *tile = C + coef_tile_index(t - 1, t, ntld) * (kCoefTile * kCoefTile);
-    double2 *out = Tnb + (size_t)t * kTnbDouble2;
-    const int i = threadIdx.x & 63;
-    const double xi = px[64 * t + i], yi = py[64 * t + i], zi = pz[64 * t + i];
-    for (int kk = k0; kk < k0 + nk; ++kk) {
-        const int j = (threadIdx.x >> 6) + 4 * kk;
-        const int js = 64 * (t - 1) + j;
-        // row atom of the tile = source j (block t-1), column atom = target i: element (l = j, s = (i - j) & 63)
-        const double2 c = tile[((i - j) & 63) * 64 + j];
-        double dx, dy, dz;
-        image_displacement<ORTHO>(bx, px[js] - xi, py[js] - yi, pz[js] - zi, dx, dy, dz);
-        const double c3 = c.x, c5 = c.y;
-        out[(j * 3 + 0) * 64 + i] = make_double2(-3.0 * dx * dx * c5 + c3, -3.0 * dx * dy * c5);
-        out[(j * 3 + 1) * 64 + i] = make_double2(-3.0 * dx * dz * c5, -3.0 * dy * dy * c5 + c3);
-        out[(j * 3 + 2) * 64 + i] = make_double2(-3.0 * dy * dz * c5, -3.0 * dz * dz * c5 + c3);
-    }
-}
-
-template <int ORTHO>
-__global__ __launch_bounds__(256) void gs_neighbor_tensor_kernel(const double2 *__restrict__ C, int ntld,
-                                                                  const double *__restrict__ px,
-                                                                  const double *__restrict__ py,
-                                                                  const double *__restrict__ pz, DevBox bx, BlockList sel,
-                                                                  double2 *__restrict__ Tnb) {
-    const int t = (sel.n > 0) ? sel.blk[blockIdx.x] : (int)blockIdx.x + 1;
-    gs_neighbor_tensor_body<ORTHO>(C, ntld, px, py, pz, bx, t, 0, 16, Tnb);
-}
 
 // ---------------------------------------------------------------------------------------------
 // M_t = (I + D L)^-1 of block t = blk[blockIdx.y] (or blockIdx.y with nsel = 0): forward substitution on the
@@ -228,7 +216,14 @@ __global__ __launch_bounds__(256) void gs_neighbor_tensor_kernel(const double2 *
 // x_b = -alpha_b r_b leaves lane b through SGPRs (v_readlane, no LDS crossbar, no reduction) and every lane a > b
 // adds T_ab x_b.  The block's tensors are expanded once into LDS from the diagonal coefficient tile (packed by
 // column: rows a > b of column b are contiguous, 6 doubles per pair).
-// grid = (192 / WAVES, nsel or nb); block = 64 WAVES; dynamic LDS = kInverseLds.
+// grid = (192 / WAVES, blocks, 3); block = 64 WAVES; dynamic LDS = kInverseLds.
+// z-slice 0: M_t of block t = sel.blk[blockIdx.y] (sel.n = 0: t = blockIdx.y, every block of the view);
+// z-slice 1: P_t = M_t D T(t,t-1) of block t = nbt.blk[blockIdx.y] (nbt.n = 0: every block t >= 1): the same forward
+//   substitution with the right-hand side D T(t,t-1)[:, (j, q)] -- wave's scalar column = source atom j of block t-1,
+//   component q -- so x_b = rhs_b - alpha_b r_b at every step and all 64 lanes carry a value from b = 0 on.
+// z-slice 2: Q_t = M_t D T(t,t-2) of block t = nbq.blk[blockIdx.y] (nbq.n = 0: every block t >= 2): the same with the
+//   tile two blocks back.
+// A workgroup whose blockIdx.y is beyond its slice's list returns at once (grid.y = the longest list).
 // ---------------------------------------------------------------------------------------------
 constexpr int kInverseLds = (kGsPairs * 6 + 4 * 64) * 8;
 // Two geometries (WAVES waves per workgroup, 192 / WAVES workgroups per block): 4 waves x 48 workgroups finishes a
@@ -241,22 +236,18 @@ __global__ __launch_bounds__(64 * WAVES) void gs_block_inverse_kernel(const doub
                                                                 const double *__restrict__ pz,
                                                                 const double *__restrict__ alpha, DevBox bx, BlockList sel,
                                                                 double *__restrict__ Minv, BlockList nbt,
-                                                                double2 *__restrict__ Tnb) {
-    // (nbt.n > 0, WAVES = 4: the expanded sub-diagonal tiles of the same move -- gs_neighbor_tensor_kernel's work, which
-    //  depends on the coefficients only -- ride in a second z-slice of this launch, a quarter of a tile per workgroup,
-    //  instead of being a launch of their own behind it)
-    if (blockIdx.z == 1) {
-        if constexpr (WAVES == 4) {
-            const int u = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;
-            if (u < 4 * nbt.n) gs_neighbor_tensor_body<ORTHO>(C, ntld, px, py, pz, bx, nbt.blk[u >> 2], 4 * (u & 3), 4, Tnb);
-        }
-        return;
-    }
+                                                                double *__restrict__ Pnb, BlockList nbq,
+                                                                double *__restrict__ Qnb, int nb) {
+    const int back = blockIdx.z;  // 0: M_t; 1: P_t (tile t-1); 2: Q_t (tile t-2)
+    const bool pmode = back >= 1;
+    const BlockList &lst = (back == 0) ? sel : (back == 1 ? nbt : nbq);
+    if (lst.n > 0 ? (int)blockIdx.y >= lst.n : (int)blockIdx.y >= nb) return;
+    const int t = (lst.n > 0) ? lst.blk[blockIdx.y] : (int)blockIdx.y;
+    if (t < back) return;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *T6 = lds;                  // column b (0..62): offset 6 (63 b - b (b - 1) / 2), then [e][a - b - 1], a > b
     double *sx = lds + kGsPairs * 6;   // [64] x, y, z, alpha of the block
     double *sy = sx + 64, *sz = sy + 64, *sal = sz + 64;
-    const int t = (sel.n > 0) ? sel.blk[blockIdx.y] : (int)blockIdx.y;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (w == 0) {
         sx[lane] = px[64 * t + lane];
@@ -285,10 +276,42 @@ __global__ __launch_bounds__(64 * WAVES) void gs_block_inverse_kernel(const doub
         }
     }
     __syncthreads();
-    const int colidx = WAVES * blockIdx.x + w;   // this wave's scalar column of M: atom c, component q
+    const int colidx = WAVES * blockIdx.x + w;   // this wave's scalar column of M (or P): atom c, component q
     const int c = colidx / 3, q = colidx % 3;
     const double al = sal[lane];
     double r0 = 0.0, r1 = 0.0, r2 = 0.0;     // lane a: sum_{c <= b < a} T_ab x_b
+    if (pmode) {
+        // right-hand side of lane a: alpha_a T(a, j)[:, q], j = source atom c of block t - back (the tile (t - back, t) holds
+        // the pair as element (l = j, s = (a - j) & 63); T is even in the displacement)
+        const double2 cf = (C + coef_tile_index(t - back, t, ntld) * (kCoefTile * kCoefTile))[((lane - c) & 63) * 64 + c];
+        const int js = 64 * (t - back) + c;
+        double dx, dy, dz;
+        image_displacement<ORTHO>(bx, px[js] - sx[lane], py[js] - sy[lane], pz[js] - sz[lane], dx, dy, dz);
+        const double dq = (q == 0) ? dx : (q == 1 ? dy : dz);
+        const double c5m = -3.0 * cf.y * dq;
+        const double h0 = al * (c5m * dx + (q == 0 ? cf.x : 0.0));
+        const double h1 = al * (c5m * dy + (q == 1 ? cf.x : 0.0));
+        const double h2 = al * (c5m * dz + (q == 2 ? cf.x : 0.0));
+        for (int b = 0; b < 63; ++b) {
+            // x_b = rhs_b - alpha_b r_b of lane b (every lane forms its own candidate; lane b's is final)
+            const double x0 = readlane_f64(fma(-al, r0, h0), b);
+            const double x1 = readlane_f64(fma(-al, r1, h1), b);
+            const double x2 = readlane_f64(fma(-al, r2, h2), b);
+            if (lane > b) {
+                const int wd = 63 - b;
+                const double *col = T6 + 6 * gs_row_offset(b) + (lane - b - 1);
+                const double xx = col[0], xy = col[wd], xz = col[2 * wd], yy = col[3 * wd], yz = col[4 * wd], zz = col[5 * wd];
+                r0 = fma(xz, x2, fma(xy, x1, fma(xx, x0, r0)));
+                r1 = fma(yz, x2, fma(yy, x1, fma(xy, x0, r1)));
+                r2 = fma(zz, x2, fma(yz, x1, fma(xz, x0, r2)));
+            }
+        }
+        double *out = (back == 1 ? Pnb : Qnb) + (size_t)t * kPnbDoubles;
+        out[pnb_index(lane, c, 0 + q)] = fma(-al, r0, h0);
+        out[pnb_index(lane, c, 3 + q)] = fma(-al, r1, h1);
+        out[pnb_index(lane, c, 6 + q)] = fma(-al, r2, h2);
+        return;
+    }
     for (int b = c; b < 63; ++b) {
         // x_b: the unit vector for b == c, else -alpha_b r_b of lane b (wave-uniform after the broadcast)
         double x0, x1, x2;
@@ -342,9 +365,63 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
         s_ok = 1;
     }
     __syncthreads();
-    const int t = s_t;
+    // tickets 0, 1: main(0), main(1); then aux(2), main(2), aux(3), main(3), ...
+    const int ticket = s_t;
+    const int t = (ticket < 2) ? ticket : 2 + ((ticket - 2) >> 1);
+    const bool aux = ticket >= 2 && !((ticket - 2) & 1);
     if (t >= p.nb) return;
     const size_t tsz = kCoefTile * kCoefTile;
+    if (aux) {
+        // ---- the auxiliary workgroup of block t: q_t = Q_t mu_{t-2}, nothing else
+        double2 qn[4][9];
+        {
+            const double2 *src = reinterpret_cast<const double2 *>(p.Qnb + (size_t)t * kPnbDoubles) + (size_t)(w * 4) * 9 * 64 + lane;
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int e = 0; e < 9; ++e) qn[m][e] = src[(m * 9 + e) * 64];
+        }
+        // far from the front: wait for an earlier block at leisure first (one lane per wave), then urgently for mu_{t-2}
+        if (t >= 7 && lane == 0) {
+            bool ok = true;
+            (void)poll_value<false>(p.mu_new + 192 * (size_t)(t - 6), p.flags, ok);
+            if (!ok) s_ok = 0;
+        }
+        double *wsm = zred + 192 * w;
+        if (lane < 24) {
+            bool ok = true;
+            const int j = w + 8 * (lane / 3), q = lane % 3;
+            wsm[lane] = poll_value<true>(p.mu_new + 192 * (size_t)(t - 2) + 64 * q + j, p.flags, ok);
+            if (!ok) s_ok = 0;
+        }
+        double cx = 0.0, cy = 0.0, cz = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const double bx_ = wsm[3 * k], by_ = wsm[3 * k + 1], bz_ = wsm[3 * k + 2];  // wave-uniform: broadcast reads
+#define QNB_E(e) ((k & 1) ? qn[k >> 1][(e)].y : qn[k >> 1][(e)].x)
+            cx = fma(QNB_E(2), bz_, fma(QNB_E(1), by_, fma(QNB_E(0), bx_, cx)));
+            cy = fma(QNB_E(5), bz_, fma(QNB_E(4), by_, fma(QNB_E(3), bx_, cy)));
+            cz = fma(QNB_E(8), bz_, fma(QNB_E(7), by_, fma(QNB_E(6), bx_, cz)));
+#undef QNB_E
+        }
+        zred[(w * 3 + 0) * 64 + lane] = cx;  // (over the staged hand-off, which this wave has read)
+        zred[(w * 3 + 1) * 64 + lane] = cy;
+        zred[(w * 3 + 2) * 64 + lane] = cz;
+        __syncthreads();
+        if (!s_ok) return;
+        if (tid < 96) {
+            const int e = 2 * tid, q = e >> 6, i = e & 63;
+            double2 acc = make_double2(0.0, 0.0);
+#pragma unroll
+            for (int g = 0; g < kChainWaves; ++g) {
+                const double2 z = *reinterpret_cast<const double2 *>(zred + (g * 3 + q) * 64 + i);
+                acc.x += z.x;
+                acc.y += z.y;
+            }
+            st_agent16(p.q_pub + 192 * (size_t)t + e, acc.x, acc.y);
+        }
+        return;
+    }
     GS_STAMP(0);
     if (p.stamps && tid == 0) p.stamps[(size_t)t * 16 + 12] = __builtin_amdgcn_s_memtime();  // shader clock, for the effective MHz
 
@@ -404,134 +481,112 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
         const double *src = (tid < 64) ? p.px : (tid < 128 ? p.py : p.pz);
         spos[tid] = src[64 * t + (tid & 63)];
     }
-    // ---- neighbour tensor tile (t, t-1) into registers: wave w takes the sources j = w, w + 8, ...
-    double2 tn[8][3];
+    // ---- P_t = M_t D T(t,t-1) into registers: wave w takes the sources j = w + 8 k; pn[m][e] = {k = 2 m, k = 2 m + 1}
+    double2 pn[4][9];
     if (t >= 1) {
-        const double2 *src = p.Tnb + (size_t)t * kTnbDouble2 + lane;
+        const double2 *src = reinterpret_cast<const double2 *>(p.Pnb + (size_t)t * kPnbDoubles) + (size_t)(w * 4) * 9 * 64 + lane;
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
+        for (int m = 0; m < 4; ++m)
 #pragma unroll
-            for (int h = 0; h < 3; ++h) tn[k][h] = src[((w + 8 * k) * 3 + h) * 64];
+            for (int e = 0; e < 9; ++e) pn[m][e] = src[(m * 9 + e) * 64];
     }
     __syncthreads();
     GS_STAMP(1);
 
     // ---- sources s = 0 .. t-2 from the pair coefficients, as they are published
-    double ax = 0.0, ay = 0.0, az = 0.0;  // this wave's share of sum_s T(t,s) mu_s; alignment tracked by `fwd_done`
-    const int ns = (p.ablate & 1) ? 0 : t - 1;
-    bool last_forward = false;
+    // Register budget: P_t takes 144 of a lane's 256 registers for the whole kernel, so the coefficient stream has ONE tile's
+    // worth of registers (8 x 16 B per lane), refilled a quarter at a time as soon as that quarter has been multiplied (3/4
+    // to 4/4 of the next 64-KB tile in flight) instead of two whole tiles, the source block's coordinates travel with its
+    // dipoles through LDS (zred is idle during this loop), and the running sums only ever rotate ONE way: wave w multiplies
+    // the steps 8 (w + n) .. 8 (w + n) + 7 (mod 64) of its n-th tile, so the sum a lane holds after a step (and one
+    // rotation) is the one its next step needs, across tile boundaries too (round 2 alternated forward and backward
+    // passes, which needs each tile whole).
+    double ax = 0.0, ay = 0.0, az = 0.0;  // lane l: this wave's share of sum_s T(t,s) mu_s for target atom (l + 8 (w + n)) & 63
+    const int ns = (p.ablate & 1) ? 0 : (t >= 2 ? t - 2 : 0);
     {
-        double2 cA[8], cB[8];
-        double sxA = 0, syA = 0, szA = 0, sxB = 0, syB = 0, szB = 0;
-        auto load_tile = [&](int s, double2 (&c)[8], double &x, double &y, double &z) {
-            const double2 *tl = p.C + coef_tile_index(s, t, p.ntld) * tsz + (size_t)(8 * w) * 64 + lane;
+        double2 c[4][2];
+        double *sps = zred;  // [3][64] coordinates of the source block being multiplied
+        auto load_quarter = [&](int n, int part) {
+            const double2 *tl = p.C + coef_tile_index(n, t, p.ntld) * tsz + (size_t)(8 * ((w + n) & 7) + 2 * part) * 64 + lane;
             if (p.ablate & 2) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) c[k] = make_double2(1e-3, 1e-4);
-                x = y = z = 1.0 * lane;
+                c[part][0] = c[part][1] = make_double2(1e-3, 1e-4);
                 return;
             }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) c[k] = tl[64 * k];
-            x = p.px[64 * s + lane];
-            y = p.py[64 * s + lane];
-            z = p.pz[64 * s + lane];
+            c[part][0] = tl[0];
+            c[part][1] = tl[64];
         };
-        // The dipoles of the next source are requested BEFORE that source's coefficient loads (a wave's loads complete
-        // in order: a poll issued behind 64 KB of tile loads waits for all of them -- measured, that made a tile cost
-        // 2.7 us instead of 1.5) and looked at after the current tile's arithmetic; a workgroup that runs behind the
+        // The dipoles (and coordinates) of the next source are requested BEFORE later coefficient loads (a wave's loads
+        // complete in order: a poll issued behind 64 KB of tile loads waits for all of them -- measured, that made a tile
+        // cost 2.7 us instead of 1.5) and looked at after the current tile's arithmetic; a workgroup that runs behind the
         // front finds them valid and never waits.
         unsigned long long spec = kGsSentinel;
+        double spec_pos = 0.0;
         auto spec_issue = [&](int s) {
-            if (tid < 192 && !(p.ablate & 4)) spec = ld_agent_u64(reinterpret_cast<const unsigned long long *>(p.mu_new) + 192 * (size_t)s + tid);
+            if (tid < 192) {
+                if (!(p.ablate & 4)) spec = ld_agent_u64(reinterpret_cast<const unsigned long long *>(p.mu_new) + 192 * (size_t)s + tid);
+                spec_pos = ((tid < 64) ? p.px : (tid < 128 ? p.py : p.pz))[64 * s + lane];
+            }
         };
-        auto fetch_mu = [&](int s) {  // mu_s -> smu[q][atom] (the published layout); false on a give-up
-            if (p.ablate & 4) return true;
-            __syncthreads();          // the previous tile's readers are done with smu
+        auto fetch_mu = [&](int s) {  // mu_s -> smu[q][atom] (the published layout), its coordinates -> sps; false on a give-up
+            __syncthreads();          // the previous tile's readers are done with smu / sps
             if (tid < 192) {
                 bool ok = true;
                 double v = __longlong_as_double((long long)spec);
-                if (spec == kGsSentinel)  // not there yet: poll (urgently when close to the neighbour)
+                if (p.ablate & 4)
+                    v = 1e-3;
+                else if (spec == kGsSentinel)  // not there yet: poll (urgently when close to the neighbour)
                     v = (t - s <= 4) ? poll_value<true>(p.mu_new + 192 * (size_t)s + tid, p.flags, ok)
                                      : poll_value<false>(p.mu_new + 192 * (size_t)s + tid, p.flags, ok);
                 smu[tid] = v;
+                sps[tid] = spec_pos;
                 if (!ok) s_ok = 0;
             }
             __syncthreads();
             return s_ok != 0;
         };
-        auto tile_product = [&](const double2 (&c)[8], double x, double y, double z, bool forward) {
-            const double mx = smu[lane], my = smu[64 + lane], mz = smu[128 + lane];
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk) {
-                const int k = forward ? kk : 7 - kk;
-                if (kk > 0) {  // the running sums follow their target atom to the neighbouring lane
-                    if (forward) {
-                        ax = wave_rotate_down(ax);
-                        ay = wave_rotate_down(ay);
-                        az = wave_rotate_down(az);
-                    } else {
-                        ax = wave_rotate_up(ax);
-                        ay = wave_rotate_up(ay);
-                        az = wave_rotate_up(az);
-                    }
-                }
-                const int jj = (lane + 8 * w + k) & 63;
-                double dx, dy, dz;
-                image_displacement<ORTHO>(p.bx, x - spos[jj], y - spos[64 + jj], z - spos[128 + jj], dx, dy, dz);
-                const double c3 = c[k].x, c5m = -3.0 * c[k].y;
-                const double wi = c5m * fma(dz, mz, fma(dy, my, dx * mx));
-                ax = fma(wi, dx, fma(c3, mx, ax));
-                ay = fma(wi, dy, fma(c3, my, ay));
-                az = fma(wi, dz, fma(c3, mz, az));
-            }
-        };
         if (ns > 0) {
             spec_issue(0);
-            load_tile(0, cA, sxA, syA, szA);
+#pragma unroll
+            for (int part = 0; part < 4; ++part) load_quarter(0, part);
         }
-        if (ns > 1) load_tile(1, cB, sxB, syB, szB);
-        for (int s = 0; s < ns; s += 2) {
-            if (!fetch_mu(s)) return;
-            if (s + 1 < ns) spec_issue(s + 1);  // (older than the tile loads issued below: lands during the arithmetic)
-            if (s >= ns - 2) GS_STAMP(s == ns - 1 ? 4 : 2);
-            tile_product(cA, sxA, syA, szA, true);
-            if (s >= ns - 2) GS_STAMP(s == ns - 1 ? 5 : 3);
-            last_forward = true;
-            if (s + 1 < ns) {
-                if (s + 2 < ns) load_tile(s + 2, cA, sxA, syA, szA);
-                if (!fetch_mu(s + 1)) return;
-                if (s + 2 < ns) spec_issue(s + 2);
-                if (s + 1 >= ns - 2) GS_STAMP(s + 1 == ns - 1 ? 4 : 2);
-                tile_product(cB, sxB, syB, szB, false);
-                if (s + 1 >= ns - 2) GS_STAMP(s + 1 == ns - 1 ? 5 : 3);
-                last_forward = false;
-                if (s + 3 < ns) load_tile(s + 3, cB, sxB, syB, szB);
+        for (int n = 0; n < ns; ++n) {
+            if (!fetch_mu(n)) return;
+            if (n + 1 < ns) spec_issue(n + 1);  // (older than the coefficient loads issued below)
+            if (n >= ns - 2) GS_STAMP(n == ns - 1 ? 4 : 2);
+            const double mx = smu[lane], my = smu[64 + lane], mz = smu[128 + lane];
+            const double x = sps[lane], y = sps[64 + lane], z = sps[128 + lane];
+            const int j0 = lane + 8 * (w + n);
+#pragma unroll
+            for (int part = 0; part < 4; ++part) {
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2) {
+                    const int jj = (j0 + 2 * part + k2) & 63;
+                    double dx, dy, dz;
+                    image_displacement<ORTHO>(p.bx, x - spos[jj], y - spos[64 + jj], z - spos[128 + jj], dx, dy, dz);
+                    const double c3 = c[part][k2].x, c5m = -3.0 * c[part][k2].y;
+                    const double wi = c5m * fma(dz, mz, fma(dy, my, dx * mx));
+                    ax = fma(wi, dx, fma(c3, mx, ax));
+                    ay = fma(wi, dy, fma(c3, my, ay));
+                    az = fma(wi, dz, fma(c3, mz, az));
+                    // the running sums follow their target atom to the neighbouring lane
+                    ax = wave_rotate_down(ax);
+                    ay = wave_rotate_down(ay);
+                    az = wave_rotate_down(az);
+                }
+                // this quarter's registers take the next tile's quarter at once: between 3/4 and 4/4 of a tile in flight
+                if (n + 1 < ns) load_quarter(n + 1, part);
             }
+            if (n >= ns - 2) GS_STAMP(n == ns - 1 ? 5 : 3);
         }
     }
-    // bring the sums back to "lane = target atom" through this wave's own scratch rows
+    __syncthreads();  // (the last tile's readers are done with zred's head, where the source coordinates sat)
+    // the sums go back to "lane = target atom" on their way to the cross-wave sum (this wave's own rows of zred)
     {
-        const int jl = (lane + 8 * w + (last_forward ? 7 : 0)) & 63;
+        const int jl = (lane + 8 * (w + ns)) & 63;
         zred[(w * 3 + 0) * 64 + jl] = ax;
         zred[(w * 3 + 1) * 64 + jl] = ay;
         zred[(w * 3 + 2) * 64 + jl] = az;
     }
-    __syncthreads();
-    ax = zred[(w * 3 + 0) * 64 + lane];
-    ay = zred[(w * 3 + 1) * 64 + lane];
-    az = zred[(w * 3 + 2) * 64 + lane];
-
-    // ---- the critical path: mu_{t-1} -> neighbour product -> v_t -> M_t v_t -> publish.
-    // Measured (in-kernel stamps, option gs_stamps, and same-box A/B runs): per block ~0.85 us of
-    // hand-off (publication to "all 192 doubles in the consumer's LDS") + ~1.8 us for the barrier-separated stages
-    // (six barriers in the first version of this section, three now).  The stages'
-    // ARITHMETIC is ~0.1 us of that -- removing both block products changed the sweep by 3 % --, so what a block
-    // costs is LDS round trips and barriers at two waves per SIMD, not flops, and the on-the-fly sources above are
-    // entirely hidden (emptying that loop changed nothing).  Tried and measured slower: every wave polling for itself
-    // (+14 %), v_readlane broadcasts instead of uniform LDS reads (+12 %), a rehearsal pass to warm the instruction
-    // cache (+17 %).  Fewer stages need the neighbour product and the inverse folded into one cached matrix
-    // (M_t D T(t,t-1), 295 KB per block): not done.
     // per-atom operands of the final steps: thread (component q = tid / 64 of atom i = tid % 64), tid < 192
     // (requested here, after the source loop, to keep them out of its register budget; they land in the slack)
     double f_al = 0.0, f_es = 0.0, f_yu = 0.0;
@@ -541,98 +596,52 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
         f_es = p.es[3 * k + w];
         f_yu = p.Srow ? f_yu_own : p.y[3 * k + w];
     }
-    double f_v = 0.0;
-    // This wave's share of the inverse, LDS -> registers, BEFORE the hand-off arrives: 18 sixteen-byte reads per lane
-    // are 147 KB through the CU's one LDS pipeline, which is slack here and critical path later (-7 % per sweep).
-    // (The registers are free now: the source loop's buffers are dead.)
-    double2 mm[18];
-    {
-        const double2 *mp = reinterpret_cast<const double2 *>(sM) + (size_t)(w * 18) * 64 + lane;
-#pragma unroll
-        for (int f2 = 0; f2 < 18; ++f2) mm[f2] = mp[f2 * 64];
-        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the reads are done before the poll below starts
-#pragma unroll
-        for (int f2 = 0; f2 < 18; ++f2) asm volatile("" : "+v"(mm[f2].x), "+v"(mm[f2].y));  // (keeps them in registers)
-    }
-    // per-lane role of this wave's four column groups (static): the column whose vector the lane multiplies and the
-    // 0 / 1 weights of the two accumulators (row lane | row 63 - lane); set up here, ahead of the hand-off
-    int mv_col[4];
-    double mv_w1[4], mv_w2[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int g = w + 8 * k;
-        const bool r1 = lane > g;
-        mv_col[k] = r1 ? g : ((g <= 30) ? 62 - g : g);
-        mv_w1[k] = r1 ? 1.0 : 0.0;
-        mv_w2[k] = r1 ? 0.0 : 1.0;
-    }
-    {
-    GS_STAMP(6);
-    if (t >= 1) {
-        // Every wave fetches the 24 doubles IT needs (its 8 source atoms x 3 components) with its first 24 lanes and
-        // spreads them through 24 words of LDS that only this wave touches: no workgroup barrier between the
-        // hand-off and the product (a wave's LDS operations execute in order), same number of polling lanes (192)
-        // as a staged copy of the whole vector.
-        double *wsm = smu + 24 * w;
-        if (lane < 24) {
-            bool ok = true;
-            const int j = w + 8 * (lane / 3), q = lane % 3;
-            wsm[lane] = poll_value<true>(p.mu_new + 192 * (size_t)(t - 1) + 64 * q + j, p.flags, ok);
-            if (!ok) s_ok = 0;
-        }
-        GS_STAMP(7);
-        if (p.ablate & 8) {  // republish what was polled (+1), nothing else
-            if (lane < 24) {
-                const int j = w + 8 * (lane / 3), q = lane % 3;
-                st_agent(p.mu_new + 192 * (size_t)t + 64 * q + j, wsm[lane] + 1.0);
-            }
-            return;
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const double bx_ = wsm[3 * k], by_ = wsm[3 * k + 1], bz_ = wsm[3 * k + 2];  // wave-uniform: broadcast reads
-            ax = fma(tn[k][1].x, bz_, fma(tn[k][0].y, by_, fma(tn[k][0].x, bx_, ax)));
-            ay = fma(tn[k][2].x, bz_, fma(tn[k][1].y, by_, fma(tn[k][0].y, bx_, ay)));
-            az = fma(tn[k][2].y, bz_, fma(tn[k][2].x, by_, fma(tn[k][1].x, bx_, az)));
-        }
-    }
-    zred[(w * 3 + 0) * 64 + lane] = ax;  // (this wave's own rows: last read by this wave, above)
-    zred[(w * 3 + 1) * 64 + lane] = ay;
-    zred[(w * 3 + 2) * 64 + lane] = az;
-    __syncthreads();  // partial sums complete; every wave is also done with its words of smu, which v_t overwrites
+    __syncthreads();
     if (!s_ok) return;
-    GS_STAMP(8);
+    GS_STAMP(6);
+
+    // ---- w_t = M_t D (e + yU - sum_{s <= t-2} T(t,s) mu_s): everything that does not need mu_{t-1}.  It hangs on
+    // mu_{t-2}, which is published one block-time before mu_{t-1}, so these three barrier-separated stages (the v_t and
+    // M_t v_t stages of round 2's critical section: 0.16 + 0.6 us by its stamps) run while block t-1 is in ITS last stage.
     if (tid < 192) {
         double sum = 0.0;
 #pragma unroll
         for (int g = 0; g < kChainWaves; ++g) sum += zred[(g * 3 + w) * 64 + lane];
-        f_v = f_al * (f_es + (f_yu - sum));  // v_t = D (e + yU - sum_{s<t} T mu_s)
-        smu[w * 64 + lane] = f_v;
+        smu[w * 64 + lane] = f_al * (f_es + (f_yu - sum));  // v = D (e + yU - sum)
     }
     __syncthreads();
-    GS_STAMP(9);
-    // M_t v_t: wave w takes the column groups g = w, w + 8, w + 16, w + 24 of the folded inverse.  A lane holds ONE 3 x 3
+    // M_t v: wave w takes the column groups g = w, w + 8, w + 16, w + 24 of the folded inverse.  A lane holds ONE 3 x 3
     // entry per group: of (row lane, column g) if lane > g [role 1], else of (row 63 - lane, column 62 - g) [role 2].  The
     // vector it multiplies is fetched with a per-lane LDS address (two distinct addresses per wave instruction), the
-    // product t = E b is formed once (9 operations) and added to the role's accumulator through a 0 / 1 weight: 15 fp64
-    // operations per group instead of 18 FMAs + 12 v_cndmask_b32 -- this stage is VALU-bound (two waves per SIMD, every
-    // instruction four cycles: 0.8 us of a block's 2.4 before, in-kernel stamps).
+    // product E b is formed once (9 operations) and added to the role's accumulator through a 0 / 1 weight.
     {
+        const double2 *mp = reinterpret_cast<const double2 *>(sM) + (size_t)(w * 18) * 64 + lane;
         double a1x = 0.0, a1y = 0.0, a1z = 0.0, a2x = 0.0, a2y = 0.0, a2z = 0.0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const double bx_ = smu[mv_col[k]], by_ = smu[64 + mv_col[k]], bz_ = smu[128 + mv_col[k]];
-#define MINV_E(e) (((9 * k + (e)) & 1) ? mm[(9 * k + (e)) >> 1].y : mm[(9 * k + (e)) >> 1].x)
-            const double tx = fma(MINV_E(2), bz_, fma(MINV_E(1), by_, MINV_E(0) * bx_));
-            const double ty = fma(MINV_E(5), bz_, fma(MINV_E(4), by_, MINV_E(3) * bx_));
-            const double tz = fma(MINV_E(8), bz_, fma(MINV_E(7), by_, MINV_E(6) * bx_));
+        for (int kb = 0; kb < 2; ++kb) {  // two groups at a time: 9 sixteen-byte reads per lane (the register budget)
+            double2 mm[9];
+#pragma unroll
+            for (int f2 = 0; f2 < 9; ++f2) mm[f2] = mp[(9 * kb + f2) * 64];
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                const int k = 2 * kb + k2;
+                const int g = w + 8 * k;
+                const bool r1 = lane > g;
+                const int col = r1 ? g : ((g <= 30) ? 62 - g : g);
+                const double w1 = r1 ? 1.0 : 0.0, w2 = r1 ? 0.0 : 1.0;
+                const double bx_ = smu[col], by_ = smu[64 + col], bz_ = smu[128 + col];
+#define MINV_E(e) (((9 * k2 + (e)) & 1) ? mm[(9 * k2 + (e)) >> 1].y : mm[(9 * k2 + (e)) >> 1].x)
+                const double tx = fma(MINV_E(2), bz_, fma(MINV_E(1), by_, MINV_E(0) * bx_));
+                const double ty = fma(MINV_E(5), bz_, fma(MINV_E(4), by_, MINV_E(3) * bx_));
+                const double tz = fma(MINV_E(8), bz_, fma(MINV_E(7), by_, MINV_E(6) * bx_));
 #undef MINV_E
-            a1x = fma(mv_w1[k], tx, a1x);
-            a1y = fma(mv_w1[k], ty, a1y);
-            a1z = fma(mv_w1[k], tz, a1z);
-            a2x = fma(mv_w2[k], tx, a2x);
-            a2y = fma(mv_w2[k], ty, a2y);
-            a2z = fma(mv_w2[k], tz, a2z);
+                a1x = fma(w1, tx, a1x);
+                a1y = fma(w1, ty, a1y);
+                a1z = fma(w1, tz, a1z);
+                a2x = fma(w2, tx, a2x);
+                a2y = fma(w2, ty, a2y);
+                a2z = fma(w2, tz, a2z);
+            }
         }
         // role-2 sums belong to row 63 - lane: mirror them across the wave
         a1x += __shfl(a2x, 63 - lane, 64);
@@ -643,23 +652,104 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
         zred[(w * 3 + 2) * 64 + lane] = a1z;
     }
     __syncthreads();
-    GS_STAMP(10);
-    // publish: 96 lanes, two adjacent elements of the planar block vector each (same component q, atoms i, i + 1)
+    // w_t: 96 lanes, two adjacent elements of the planar block vector each (same component q, atoms i, i + 1), in the
+    // registers of the lanes that will publish
+    double2 wt = make_double2(0.0, 0.0);
     if (tid < 96) {
         const int e = 2 * tid;
-        double2 mu = *reinterpret_cast<const double2 *>(smu + e);  // v_t
+        wt = *reinterpret_cast<const double2 *>(smu + e);  // v
         const int q = e >> 6, i = e & 63;
 #pragma unroll
         for (int g = 0; g < kChainWaves; ++g) {
             const double2 z = *reinterpret_cast<const double2 *>(zred + (g * 3 + q) * 64 + i);
-            mu.x += z.x;
-            mu.y += z.y;
+            wt.x += z.x;
+            wt.y += z.y;
+        }
+    }
+    __syncthreads();  // zred is free again: every wave stages its share of the hand-off in its own rows below
+    GS_STAMP(7);
+
+    // ---- the critical path: mu_{t-1} -> P_t mu_{t-1} -> cross-wave sum -> publish.  One barrier.
+    if (t >= 1) {
+        // Every wave fetches the 24 doubles IT needs (its 8 source atoms x 3 components) with its first 24 lanes and
+        // spreads them through 24 words of LDS that only this wave touches (the head of its own zred rows): no workgroup
+        // barrier between the hand-off and the product (a wave's LDS operations execute in order).
+        double *wsm = zred + 192 * w;
+        if (lane < 24) {
+            bool ok = true;
+            const int j = w + 8 * (lane / 3), q = lane % 3;
+            wsm[lane] = poll_value<true>(p.mu_new + 192 * (size_t)(t - 1) + 64 * q + j, p.flags, ok);
+            if (!ok) s_ok = 0;
+        }
+        GS_STAMP(8);
+        // q_t (published about one hand-off earlier by the auxiliary workgroup): requested now by the lanes that will
+        // publish, looked at behind the product
+        unsigned long long qa = 0ull, qb = 0ull;
+        if (t >= 2 && tid < 96) {
+            const unsigned long long *qp = reinterpret_cast<const unsigned long long *>(p.q_pub) + 192 * (size_t)t + 2 * tid;
+            qa = ld_agent_u64(qp);
+            qb = ld_agent_u64(qp + 1);
+        }
+        if (p.ablate & 8) {  // republish what was polled (+1), nothing else
+            if (lane < 24) {
+                const int j = w + 8 * (lane / 3), q = lane % 3;
+                st_agent(p.mu_new + 192 * (size_t)t + 64 * q + j, wsm[lane] + 1.0);
+            }
+            return;
+        }
+        double bx_[8], by_[8], bz_[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {  // wave-uniform: broadcast reads
+            bx_[k] = wsm[3 * k];
+            by_[k] = wsm[3 * k + 1];
+            bz_[k] = wsm[3 * k + 2];
+        }
+        double cx = 0.0, cy = 0.0, cz = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+#define PNB_E(e) ((k & 1) ? pn[k >> 1][(e)].y : pn[k >> 1][(e)].x)
+            cx = fma(PNB_E(2), bz_[k], fma(PNB_E(1), by_[k], fma(PNB_E(0), bx_[k], cx)));
+            cy = fma(PNB_E(5), bz_[k], fma(PNB_E(4), by_[k], fma(PNB_E(3), bx_[k], cy)));
+            cz = fma(PNB_E(8), bz_[k], fma(PNB_E(7), by_[k], fma(PNB_E(6), bx_[k], cz)));
+#undef PNB_E
+        }
+        zred[(w * 3 + 0) * 64 + lane] = cx;  // (over the staged hand-off, which this wave has read)
+        zred[(w * 3 + 1) * 64 + lane] = cy;
+        zred[(w * 3 + 2) * 64 + lane] = cz;
+        if (t >= 2 && tid < 96) {
+            bool ok = true;
+            double q0 = __longlong_as_double((long long)qa), q1 = __longlong_as_double((long long)qb);
+            if (qa == kGsSentinel) q0 = poll_value<true>(p.q_pub + 192 * (size_t)t + 2 * tid, p.flags, ok);
+            if (qb == kGsSentinel) q1 = poll_value<true>(p.q_pub + 192 * (size_t)t + 2 * tid + 1, p.flags, ok);
+            if (!ok) s_ok = 0;
+            wt.x -= q0;
+            wt.y -= q1;
+        }
+        __syncthreads();
+        if (!s_ok) return;
+        GS_STAMP(9);
+    }
+    // publish: mu_t = w_t - P_t mu_{t-1}
+    if (tid < 96) {
+        const int e = 2 * tid;
+        double2 mu = wt;
+        if (t >= 1) {
+            const int q = e >> 6, i = e & 63;
+            double2 acc = make_double2(0.0, 0.0);
+#pragma unroll
+            for (int g = 0; g < kChainWaves; ++g) {
+                const double2 z = *reinterpret_cast<const double2 *>(zred + (g * 3 + q) * 64 + i);
+                acc.x += z.x;
+                acc.y += z.y;
+            }
+            mu.x -= acc.x;
+            mu.y -= acc.y;
         }
         if (t != p.fault_block) st_agent16(p.mu_new + 192 * (size_t)t + e, mu.x, mu.y);
         *reinterpret_cast<double2 *>(smu + e) = mu;
     }
+    GS_STAMP(10);
     __syncthreads();
-    }
     GS_STAMP(11);
     if (p.stamps && tid == 0) p.stamps[(size_t)t * 16 + 13] = __builtin_amdgcn_s_memtime();
     double dd = 0.0, nn = 0.0;

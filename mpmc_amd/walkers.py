@@ -72,6 +72,7 @@ class WalkerAverages:
         self.reducer = reducer
         self.local = np.zeros(len(FIELDS))
         self.pooled = np.zeros(len(FIELDS))
+        self.own = np.zeros(len(FIELDS))  # this walker's own totals (never reduced): tells copies of a walker apart
         self._in_flight = False
         self.reductions = 0
 
@@ -90,6 +91,7 @@ class WalkerAverages:
         in MPI_Gather here, mc.c:431)."""
         v = self.local.copy()
         self.local[:] = 0.0
+        self.own += v
         if self.reducer is not None:
             self._finish_pending()
             self.reducer.begin(v)
@@ -97,6 +99,9 @@ class WalkerAverages:
             self.reductions += 1
         else:
             self.pooled += v
+
+    def own_mean_energy(self):
+        return float(self.own[1] / max(self.own[0], 1.0))
 
     def summary(self):
         self._finish_pending()

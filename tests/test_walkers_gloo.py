@@ -154,3 +154,45 @@ def test_bench_gpus_2_without_gpus_fails_loudly():
 def test_bench_refuses_gpus_that_disagree_with_world_size():
     r = _bench("--gpus", "4", "--launch-check", env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "must agree" in (r.stderr + r.stdout)
+
+
+def test_launcher_reports_a_rank_that_exits_and_does_not_wait_for_ever():
+    """One child exits non-zero before the rendezvous: the launcher returns non-zero within its deadline, names the rank's
+    exit code and relays its last stderr lines; the surviving rank (blocked in the rendezvous) is killed -- exactly the
+    PIDs the launcher started."""
+    import time
+
+    t0 = time.time()
+    r = _bench("--gpus", "2", "--launch-check", "--steps", "10", "--corrtime", "5", "--launch-fault", "exit:1", "--deadline", "25",
+               timeout=120)
+    assert r.returncode != 0
+    assert time.time() - t0 < 90
+    assert "rank exit codes" in r.stderr and "3" in r.stderr
+    assert "[rank 1] launch-check: rank 1 exits on request" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_launcher_deadline_covers_rank_0_too():
+    """Rank 0 itself never comes back (the case of a stuck communicator set-up on an 8-GPU node): round 2's launcher waited
+    on it for ever.  Now every rank shares one deadline."""
+    import time
+
+    t0 = time.time()
+    r = _bench("--gpus", "2", "--launch-check", "--steps", "10", "--corrtime", "5", "--launch-fault", "hang:0", "--deadline", "15",
+               timeout=120)
+    assert r.returncode != 0
+    assert 10 < time.time() - t0 < 90
+    assert "deadline" in r.stderr and "were killed" in r.stderr
+
+
+def test_own_totals_tell_copies_of_a_walker_apart():
+    from mpmc_amd.walkers import WalkerAverages
+
+    a, b = WalkerAverages(), WalkerAverages()
+    for w, e in ((a, -10.0), (b, -10.0)):
+        w.add(e, 0, 0, 0, 0, 1)
+        w.reduce()
+    assert a.own_mean_energy() == b.own_mean_energy()  # what bench.py refuses (exit code 4) between two ranks
+    b.add(-11.0, 0, 0, 0, 0, 1)
+    b.reduce()
+    assert a.own_mean_energy() != b.own_mean_energy()
