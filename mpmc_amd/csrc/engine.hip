@@ -236,6 +236,8 @@ struct mpmc_hip_ctx {
     unsigned long long resident_calls = 0, resident_fallbacks = 0;
     int opt_gs_ablate = 0;                 // timing-only ablations of the chain kernel (wrong results; tools/gs_ablate.py)
     int opt_gs_stamps = 0;                 // diagnostic: time stamps inside the chain kernel (printed by the sweep)
+    int opt_inv_stamps = 0;                // diagnostic: time stamps inside gs_block_inverse_kernel (main stream launches)
+    unsigned long long *d_istamps = nullptr;
     int gs_qoff = 0;                       // offset (doubles) of the q_t hand-off buffer inside a view's mupub
     unsigned long long *d_stamps = nullptr;
     int gs_sweeps_this_call = 0;
@@ -543,6 +545,8 @@ extern "C" int mpmc_hip_set_option(mpmc_hip_ctx *c, const char *name, int value)
         c->opt_fuse_moves = value;  // 0: apply_moves_kernel + update_coef_kernel as two launches (A/B; bit-identical)
     else if (!strcmp(name, "resident_fault"))
         c->opt_res_fault = value;  // test hook: the next resident launch loses a hand-off (-> fallback)
+    else if (!strcmp(name, "inv_stamps"))
+        c->opt_inv_stamps = value;
     else if (!strcmp(name, "resident_stamps"))
         c->opt_res_stamps = value;
     else if (!strcmp(name, "split_record"))
@@ -612,6 +616,10 @@ extern "C" int mpmc_hip_create(mpmc_hip_ctx **out, int device, int max_atoms) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(gs_block_inverse_kernel<0, 4>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, kInverseLds));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(gs_block_inverse_kernel<1, 4>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, kInverseLds));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(gs_block_inverse_kernel<0, 8>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, kInverseLds));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(gs_block_inverse_kernel<1, 8>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, kInverseLds));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(gs_block_inverse_kernel<0, 16>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, kInverseLds));
@@ -727,7 +735,7 @@ extern "C" void mpmc_hip_destroy(mpmc_hip_ctx *c) {
     void *dptrs[] = {c->d_x,   c->d_y,     c->d_z,     c->d_q,    c->d_alpha, c->d_eps,      c->d_sig,
                      c->d_molmass, c->d_mol, c->d_flags, c->d_es, c->d_mu,    c->d_efind,    c->d_efchg,
                      c->d_tmp3, c->d_rank, c->d_rank_used, c->d_rankcnt, c->d_errmax, c->d_pairpart, c->d_fieldpart, c->d_kvec,
-                     c->d_res,  c->d_kvecf, c->d_sf, c->d_lrcpart, c->d_rankpart, c->d_sfpart, c->d_recipsum};
+                     c->d_res,  c->d_kvecf, c->d_sf, c->d_lrcpart, c->d_rankpart, c->d_sfpart, c->d_recipsum, c->d_istamps};
     for (void *p : dptrs)
         if (p) hipFree(p);
     for (SweepView &v : c->view) {

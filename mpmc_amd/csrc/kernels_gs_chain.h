@@ -201,6 +201,33 @@ __device__ __forceinline__ double wave_rotate_up(double v) {
     return __hiloint2double(hi, lo);
 }
 
+// The three 16-byte words of one pair's tensor from LDS, REQUESTED here and WAITED FOR in lds_tensor_wait(): hipcc sinks
+// ordinary LDS loads to their first use, which puts the ~120-cycle round trip back into the dependent chain the
+// prefetch was written to keep it out of (seen in the ISA: ds_read_b128 x 3, s_waitcnt lgkmcnt(0), v_fmac ...).
+typedef double __attribute__((ext_vector_type(2))) gs_d2_t;
+struct LdsTensor {
+    gs_d2_t a, b, c;  // {xx, xy}, {xz, yy}, {yz, zz}
+};
+#ifndef INV_ABLATE
+#define INV_ABLATE 0  // timing-only experiments (tools/ab builds): 1 = no LDS reads in the substitution, 2 = no lane broadcasts
+#endif
+__device__ __forceinline__ void lds_tensor_request(const double *p, LdsTensor &t) {
+    const unsigned addr = (unsigned)(unsigned long long)p;  // (a generic pointer into LDS: the low word is the LDS address)
+#if INV_ABLATE == 1
+    t.a = t.b = t.c = gs_d2_t{1e-3 * (double)(addr & 255u), 2e-3};
+    return;
+#endif
+    asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %3 offset:32"
+                 : "=&v"(t.a), "=&v"(t.b), "=&v"(t.c)
+                 : "v"(addr));
+}
+__device__ __forceinline__ void lds_tensor_wait(LdsTensor &t) {
+#if INV_ABLATE == 1
+    return;
+#endif
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t.a), "+v"(t.b), "+v"(t.c));
+}
+
 constexpr int kMaxBlockList = 48;
 struct BlockList {
     int n;
@@ -225,7 +252,7 @@ struct BlockList {
 //   tile two blocks back.
 // A workgroup whose blockIdx.y is beyond its slice's list returns at once (grid.y = the longest list).
 // ---------------------------------------------------------------------------------------------
-constexpr int kInverseLds = (kGsPairs * 6 + 4 * 64) * 8;
+constexpr int kInverseLds = (kGsPairs * 6 + 8 + 4 * 64) * 8;  // tensors + one all-zero pair (padded to 64 B) + x, y, z, alpha
 // Two geometries (WAVES waves per workgroup, 192 / WAVES workgroups per block): 4 waves x 48 workgroups finishes a
 // couple of blocks soonest (17.5 vs 24 us: the moved atoms' blocks of view 0 are on the step's critical path), 16 waves
 // x 12 workgroups repeats the tile expansion a quarter as often and rebuilds a whole view 3.6x faster (46 vs 166 us).
@@ -237,7 +264,15 @@ __global__ __launch_bounds__(64 * WAVES) void gs_block_inverse_kernel(const doub
                                                                 const double *__restrict__ alpha, DevBox bx, BlockList sel,
                                                                 double *__restrict__ Minv, BlockList nbt,
                                                                 double *__restrict__ Pnb, BlockList nbq,
-                                                                double *__restrict__ Qnb, int nb) {
+                                                                double *__restrict__ Qnb, int nb,
+                                                                unsigned long long *__restrict__ stamps) {
+    // diagnostic (option "inv_stamps"): per workgroup, s_memrealtime at start / loads landed / expanded / solved
+    const int wg_ = ((int)blockIdx.z * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + (int)blockIdx.x;
+#define INV_STAMP(k)                                                                                  \
+    do {                                                                                              \
+        if (stamps && threadIdx.x == 0) stamps[(size_t)wg_ * 4 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+    INV_STAMP(0);
     const int back = blockIdx.z;  // 0: M_t; 1: P_t (tile t-1); 2: Q_t (tile t-2)
     const bool pmode = back >= 1;
     const BlockList &lst = (back == 0) ? sel : (back == 1 ? nbt : nbq);
@@ -245,10 +280,37 @@ __global__ __launch_bounds__(64 * WAVES) void gs_block_inverse_kernel(const doub
     const int t = (lst.n > 0) ? lst.blk[blockIdx.y] : (int)blockIdx.y;
     if (t < back) return;
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *T6 = lds;                  // column b (0..62): offset 6 (63 b - b (b - 1) / 2), then [e][a - b - 1], a > b
-    double *sx = lds + kGsPairs * 6;   // [64] x, y, z, alpha of the block
+    // pair (a, b), a > b, at index off(b) + a - b - 1 (off(b) = 63 b - b (b - 1) / 2): 6 adjacent doubles {xx, xy, xz, yy, yz,
+    // zz} = three 16-byte words, rows a of a column b contiguous; index kGsPairs = an all-zero pair, which the lanes a <= b
+    // of a substitution step read instead (no exec-mask branch in the 63-step chain)
+    double *T6 = lds;
+    double *sx = lds + kGsPairs * 6 + 8;   // [64] x, y, z, alpha of the block
     double *sy = sx + 64, *sz = sy + 64, *sal = sz + 64;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int colidx = WAVES * blockIdx.x + w;   // this wave's scalar column of M (or P, Q): atom c, component q
+    const int c = colidx / 3, q = colidx % 3;
+    // Every global load of the workgroup is issued up front (round 2 loaded the diagonal tile row by row inside the
+    // expansion loop, one dependent ~0.6 us round trip per row: 16 of them were most of the kernel's 17 us).
+    // pair (a, b), a > b, is element (l = b, s = a - b) of the diagonal tile; wave w expands the rows s = 1 + w + k WAVES
+    const double2 *tile = C + coef_tile_index(t, t, ntld) * (kCoefTile * kCoefTile);
+    constexpr int kRows = (63 + WAVES - 1) / WAVES;
+    double2 cfd[kRows];
+#pragma unroll
+    for (int k = 0; k < kRows; ++k) {
+        const int sr = 1 + w + k * WAVES;
+        cfd[k] = (sr < 64 && lane + sr < 64) ? tile[sr * 64 + lane] : make_double2(0.0, 0.0);
+    }
+    // (P / Q: the coefficient of the pair (lane a of block t, source atom c of block t - back) -- the tile (t - back, t)
+    //  holds it as element (l = c, s = (a - c) & 63) -- and that atom's coordinates)
+    double2 cfn = make_double2(0.0, 0.0);
+    double pjx = 0.0, pjy = 0.0, pjz = 0.0;
+    if (pmode) {
+        cfn = (C + coef_tile_index(t - back, t, ntld) * (kCoefTile * kCoefTile))[((lane - c) & 63) * 64 + c];
+        const int js = 64 * (t - back) + c;
+        pjx = px[js];
+        pjy = py[js];
+        pjz = pz[js];
+    }
     if (w == 0) {
         sx[lane] = px[64 * t + lane];
         sy[lane] = py[64 * t + lane];
@@ -256,83 +318,91 @@ __global__ __launch_bounds__(64 * WAVES) void gs_block_inverse_kernel(const doub
         sal[lane] = alpha[64 * t + lane];
     }
     __syncthreads();
-    // expand the strictly lower triangle: pair (a, b), a > b, is element (l = b, s = a - b) of the diagonal tile
-    const double2 *tile = C + coef_tile_index(t, t, ntld) * (kCoefTile * kCoefTile);
-    for (int s = 1 + w; s < 64; s += WAVES) {
-        const int b = lane, a = lane + s;
-        if (a < 64) {
-            const double2 c = tile[s * 64 + b];
+    INV_STAMP(1);
+    // expand the strictly lower triangle
+    if (threadIdx.x < 8) T6[6 * kGsPairs + threadIdx.x] = 0.0;
+#pragma unroll
+    for (int k = 0; k < kRows; ++k) {
+        const int sr = 1 + w + k * WAVES;
+        const int b = lane, a = lane + sr;
+        if (sr < 64 && a < 64) {
             double dx, dy, dz;
             image_displacement<ORTHO>(bx, sx[b] - sx[a], sy[b] - sy[a], sz[b] - sz[a], dx, dy, dz);
-            const double c3 = c.x, c5 = c.y;
-            const int wd = 63 - b;
-            double *col = T6 + 6 * gs_row_offset(b) + (a - b - 1);
-            col[0 * wd] = -3.0 * dx * dx * c5 + c3;
-            col[1 * wd] = -3.0 * dx * dy * c5;
-            col[2 * wd] = -3.0 * dx * dz * c5;
-            col[3 * wd] = -3.0 * dy * dy * c5 + c3;
-            col[4 * wd] = -3.0 * dy * dz * c5;
-            col[5 * wd] = -3.0 * dz * dz * c5 + c3;
+            const double c3 = cfd[k].x, c5 = cfd[k].y;
+            double2 *dst = reinterpret_cast<double2 *>(T6 + 6 * (gs_row_offset(b) + (a - b - 1)));
+            dst[0] = make_double2(-3.0 * dx * dx * c5 + c3, -3.0 * dx * dy * c5);
+            dst[1] = make_double2(-3.0 * dx * dz * c5, -3.0 * dy * dy * c5 + c3);
+            dst[2] = make_double2(-3.0 * dy * dz * c5, -3.0 * dz * dz * c5 + c3);
         }
     }
     __syncthreads();
-    const int colidx = WAVES * blockIdx.x + w;   // this wave's scalar column of M (or P): atom c, component q
-    const int c = colidx / 3, q = colidx % 3;
+    INV_STAMP(2);
     const double al = sal[lane];
     double r0 = 0.0, r1 = 0.0, r2 = 0.0;     // lane a: sum_{c <= b < a} T_ab x_b
+    // The substitution is a 63-step dependent chain per column, so a step must hold nothing but the chain itself: the
+    // tensors of step b + 1 are requested from LDS BEFORE step b's arithmetic (they do not depend on it; round 2 read them,
+    // and alpha_b, inside the step: two LDS round trips of ~120 cycles each per step were most of the kernel's 17-20 us),
+    // alpha_b comes out of lane b's register with the same v_readlane as r_b, and lanes a <= b read the all-zero pair.
+    auto tensor_of = [&](int b) {
+        const int pidx = (lane > b) ? gs_row_offset(b) + (lane - b - 1) : kGsPairs;
+        return T6 + 6 * pidx;
+    };
     if (pmode) {
-        // right-hand side of lane a: alpha_a T(a, j)[:, q], j = source atom c of block t - back (the tile (t - back, t) holds
-        // the pair as element (l = j, s = (a - j) & 63); T is even in the displacement)
-        const double2 cf = (C + coef_tile_index(t - back, t, ntld) * (kCoefTile * kCoefTile))[((lane - c) & 63) * 64 + c];
-        const int js = 64 * (t - back) + c;
+        // right-hand side of lane a: alpha_a T(a, j)[:, q], j = source atom c of block t - back (T is even in the displacement)
+        const double2 cf = cfn;
         double dx, dy, dz;
-        image_displacement<ORTHO>(bx, px[js] - sx[lane], py[js] - sy[lane], pz[js] - sz[lane], dx, dy, dz);
+        image_displacement<ORTHO>(bx, pjx - sx[lane], pjy - sy[lane], pjz - sz[lane], dx, dy, dz);
         const double dq = (q == 0) ? dx : (q == 1 ? dy : dz);
         const double c5m = -3.0 * cf.y * dq;
         const double h0 = al * (c5m * dx + (q == 0 ? cf.x : 0.0));
         const double h1 = al * (c5m * dy + (q == 1 ? cf.x : 0.0));
         const double h2 = al * (c5m * dz + (q == 2 ? cf.x : 0.0));
+        LdsTensor nx;
+        lds_tensor_request(tensor_of(0), nx);
         for (int b = 0; b < 63; ++b) {
             // x_b = rhs_b - alpha_b r_b of lane b (every lane forms its own candidate; lane b's is final)
+#if INV_ABLATE == 2
+            const double x0 = fma(-al, r0, h0), x1 = fma(-al, r1, h1), x2 = fma(-al, r2, h2);
+#else
             const double x0 = readlane_f64(fma(-al, r0, h0), b);
             const double x1 = readlane_f64(fma(-al, r1, h1), b);
             const double x2 = readlane_f64(fma(-al, r2, h2), b);
-            if (lane > b) {
-                const int wd = 63 - b;
-                const double *col = T6 + 6 * gs_row_offset(b) + (lane - b - 1);
-                const double xx = col[0], xy = col[wd], xz = col[2 * wd], yy = col[3 * wd], yz = col[4 * wd], zz = col[5 * wd];
-                r0 = fma(xz, x2, fma(xy, x1, fma(xx, x0, r0)));
-                r1 = fma(yz, x2, fma(yy, x1, fma(xy, x0, r1)));
-                r2 = fma(zz, x2, fma(yz, x1, fma(xz, x0, r2)));
-            }
+#endif
+            lds_tensor_wait(nx);
+            const LdsTensor tt = nx;
+            lds_tensor_request(tensor_of(b + 1 < 63 ? b + 1 : 62), nx);  // step b + 1's, behind which step b computes
+            __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise moves the request behind the arithmetic)
+            r0 = fma(tt.b.x, x2, fma(tt.a.y, x1, fma(tt.a.x, x0, r0)));
+            r1 = fma(tt.c.x, x2, fma(tt.b.y, x1, fma(tt.a.y, x0, r1)));
+            r2 = fma(tt.c.y, x2, fma(tt.c.x, x1, fma(tt.b.x, x0, r2)));
         }
+        lds_tensor_wait(nx);  // (nothing of this wave's stays in flight)
         double *out = (back == 1 ? Pnb : Qnb) + (size_t)t * kPnbDoubles;
         out[pnb_index(lane, c, 0 + q)] = fma(-al, r0, h0);
         out[pnb_index(lane, c, 3 + q)] = fma(-al, r1, h1);
         out[pnb_index(lane, c, 6 + q)] = fma(-al, r2, h2);
+        INV_STAMP(3);
         return;
     }
-    for (int b = c; b < 63; ++b) {
-        // x_b: the unit vector for b == c, else -alpha_b r_b of lane b (wave-uniform after the broadcast)
-        double x0, x1, x2;
-        if (b == c) {
-            x0 = (q == 0) ? 1.0 : 0.0;
-            x1 = (q == 1) ? 1.0 : 0.0;
-            x2 = (q == 2) ? 1.0 : 0.0;
-        } else {
-            const double nb_al = -sal[b];
-            x0 = nb_al * readlane_f64(r0, b);
-            x1 = nb_al * readlane_f64(r1, b);
-            x2 = nb_al * readlane_f64(r2, b);
+    {
+        // x_c: the unit vector; x_b = -alpha_b r_b of lane b afterwards (wave-uniform after the broadcast)
+        double x0 = (q == 0) ? 1.0 : 0.0, x1 = (q == 1) ? 1.0 : 0.0, x2 = (q == 2) ? 1.0 : 0.0;
+        LdsTensor nx;
+        lds_tensor_request(tensor_of(c < 63 ? c : 62), nx);
+        for (int b = c; b < 63; ++b) {
+            lds_tensor_wait(nx);
+            const LdsTensor tt = nx;
+            lds_tensor_request(tensor_of(b + 1 < 63 ? b + 1 : 62), nx);  // step b + 1's, behind which step b computes
+            __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise moves the request behind the arithmetic)
+            r0 = fma(tt.b.x, x2, fma(tt.a.y, x1, fma(tt.a.x, x0, r0)));
+            r1 = fma(tt.c.x, x2, fma(tt.b.y, x1, fma(tt.a.y, x0, r1)));
+            r2 = fma(tt.c.y, x2, fma(tt.c.x, x1, fma(tt.b.x, x0, r2)));
+            const double nb_al = -readlane_f64(al, b + 1 < 64 ? b + 1 : 63);
+            x0 = nb_al * readlane_f64(r0, b + 1);
+            x1 = nb_al * readlane_f64(r1, b + 1);
+            x2 = nb_al * readlane_f64(r2, b + 1);
         }
-        if (lane > b) {
-            const int wd = 63 - b;
-            const double *col = T6 + 6 * gs_row_offset(b) + (lane - b - 1);
-            const double xx = col[0], xy = col[wd], xz = col[2 * wd], yy = col[3 * wd], yz = col[4 * wd], zz = col[5 * wd];
-            r0 = fma(xz, x2, fma(xy, x1, fma(xx, x0, r0)));
-            r1 = fma(yz, x2, fma(yy, x1, fma(xy, x0, r1)));
-            r2 = fma(zz, x2, fma(yz, x1, fma(xz, x0, r2)));
-        }
+        lds_tensor_wait(nx);
     }
     if (lane > c) {
         double *out = Minv + (size_t)t * kMinvDoubles;
@@ -340,6 +410,8 @@ __global__ __launch_bounds__(64 * WAVES) void gs_block_inverse_kernel(const doub
         out[minv_index(lane, c, 3 + q)] = -al * r1;
         out[minv_index(lane, c, 6 + q)] = -al * r2;
     }
+    INV_STAMP(3);
+#undef INV_STAMP
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -467,7 +539,20 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
         }
         __syncthreads();  // (M_t is staged over these words next)
     }
-    // ---- stage M_t (folded layout, 16-B loads) and the target block's coordinates
+    // ---- the target block's coordinates and per-atom operands (small, requested first), then M_t (folded layout, 16-B
+    // loads) into LDS.  The operands of the final steps (component q = tid / 64 of atom i = tid % 64) are PARKED in the rows
+    // of zred the source loop does not use, so that neither their registers burden that loop nor their load latency
+    // (~0.6 us) sits between the last source and w_t.
+    if (tid < 192) {
+        const double *src = (tid < 64) ? p.px : (tid < 128 ? p.py : p.pz);
+        const int k = 64 * t + lane;
+        const double v_pos = src[k], v_al = p.alpha[k], v_es = p.es[3 * k + w];
+        const double v_yu = p.Srow ? f_yu_own : p.y[3 * k + w];
+        spos[tid] = v_pos;
+        zred[192 + tid] = v_al;
+        zred[384 + tid] = v_es;
+        zred[576 + tid] = v_yu;
+    }
     {
         const double2 *src = reinterpret_cast<const double2 *>(p.Minv + (size_t)t * kMinvDoubles);
         double2 *dst = reinterpret_cast<double2 *>(sM);
@@ -477,11 +562,12 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
 #pragma unroll
         for (int k = 0; k < kMinvDoubles / 2 / kChainThreads; ++k) dst[k * kChainThreads + tid] = r[k];
     }
-    if (tid < 192) {
-        const double *src = (tid < 64) ? p.px : (tid < 128 ? p.py : p.pz);
-        spos[tid] = src[64 * t + (tid & 63)];
-    }
-    // ---- P_t = M_t D T(t,t-1) into registers: wave w takes the sources j = w + 8 k; pn[m][e] = {k = 2 m, k = 2 m + 1}
+    __syncthreads();
+    GS_STAMP(1);
+    // ---- P_t = M_t D T(t,t-1) into registers: wave w takes the sources j = w + 8 k; pn[m][e] = {k = 2 m, k = 2 m + 1}.
+    // Requested BEHIND the barrier that ends the staging of M_t: nothing waits for these 288 KB until the product with
+    // mu_{t-1}, so the first blocks of a sweep (whose turn comes before the loads have landed) can form w_t meanwhile --
+    // in front of the barrier they delayed every block's staging by 2.2 us (stamps), i.e. the start of every sweep.
     double2 pn[4][9];
     if (t >= 1) {
         const double2 *src = reinterpret_cast<const double2 *>(p.Pnb + (size_t)t * kPnbDoubles) + (size_t)(w * 4) * 9 * 64 + lane;
@@ -490,8 +576,6 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
 #pragma unroll
             for (int e = 0; e < 9; ++e) pn[m][e] = src[(m * 9 + e) * 64];
     }
-    __syncthreads();
-    GS_STAMP(1);
 
     // ---- sources s = 0 .. t-2 from the pair coefficients, as they are published
     // Register budget: P_t takes 144 of a lane's 256 registers for the whole kernel, so the coefficient stream has ONE tile's
@@ -519,18 +603,26 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
         // complete in order: a poll issued behind 64 KB of tile loads waits for all of them -- measured, that made a tile
         // cost 2.7 us instead of 1.5) and looked at after the current tile's arithmetic; a workgroup that runs behind the
         // front finds them valid and never waits.
-        unsigned long long spec = kGsSentinel;
+        // A workgroup that keeps pace with the front asks too early (mu_{s+1} is published one block-time after mu_s): the
+        // request is repeated half-way through the tile's arithmetic (spec2), which saves the ~0.5 us of a dependent load
+        // per source whenever the value has arrived in between.
+        unsigned long long spec = kGsSentinel, spec2 = kGsSentinel;
         double spec_pos = 0.0;
         auto spec_issue = [&](int s) {
             if (tid < 192) {
                 if (!(p.ablate & 4)) spec = ld_agent_u64(reinterpret_cast<const unsigned long long *>(p.mu_new) + 192 * (size_t)s + tid);
                 spec_pos = ((tid < 64) ? p.px : (tid < 128 ? p.py : p.pz))[64 * s + lane];
             }
+            spec2 = kGsSentinel;
+        };
+        auto spec_again = [&](int s) {
+            if (tid < 192 && !(p.ablate & 4)) spec2 = ld_agent_u64(reinterpret_cast<const unsigned long long *>(p.mu_new) + 192 * (size_t)s + tid);
         };
         auto fetch_mu = [&](int s) {  // mu_s -> smu[q][atom] (the published layout), its coordinates -> sps; false on a give-up
             __syncthreads();          // the previous tile's readers are done with smu / sps
             if (tid < 192) {
                 bool ok = true;
+                if (spec == kGsSentinel) spec = spec2;
                 double v = __longlong_as_double((long long)spec);
                 if (p.ablate & 4)
                     v = 1e-3;
@@ -575,26 +667,25 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
                 }
                 // this quarter's registers take the next tile's quarter at once: between 3/4 and 4/4 of a tile in flight
                 if (n + 1 < ns) load_quarter(n + 1, part);
+                if (part == 2 && n + 1 < ns) spec_again(n + 1);
             }
             if (n >= ns - 2) GS_STAMP(n == ns - 1 ? 5 : 3);
         }
     }
-    __syncthreads();  // (the last tile's readers are done with zred's head, where the source coordinates sat)
+    // the parked per-atom operands come back before zred is overwritten
+    double f_al = 0.0, f_es = 0.0, f_yu = 0.0;
+    if (tid < 192) {
+        f_al = zred[192 + tid];
+        f_es = zred[384 + tid];
+        f_yu = zred[576 + tid];
+    }
+    __syncthreads();  // (everybody is done with zred: source coordinates at its head, the parked operands behind them)
     // the sums go back to "lane = target atom" on their way to the cross-wave sum (this wave's own rows of zred)
     {
         const int jl = (lane + 8 * (w + ns)) & 63;
         zred[(w * 3 + 0) * 64 + jl] = ax;
         zred[(w * 3 + 1) * 64 + jl] = ay;
         zred[(w * 3 + 2) * 64 + jl] = az;
-    }
-    // per-atom operands of the final steps: thread (component q = tid / 64 of atom i = tid % 64), tid < 192
-    // (requested here, after the source loop, to keep them out of its register budget; they land in the slack)
-    double f_al = 0.0, f_es = 0.0, f_yu = 0.0;
-    if (tid < 192) {
-        const int k = 64 * t + lane;
-        f_al = p.alpha[k];
-        f_es = p.es[3 * k + w];
-        f_yu = p.Srow ? f_yu_own : p.y[3 * k + w];
     }
     __syncthreads();
     if (!s_ok) return;
@@ -675,21 +766,23 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
         // spreads them through 24 words of LDS that only this wave touches (the head of its own zred rows): no workgroup
         // barrier between the hand-off and the product (a wave's LDS operations execute in order).
         double *wsm = zred + 192 * w;
-        if (lane < 24) {
+        // ... and, with lanes 32..55, 24 of the 192 doubles of q_t (published about one hand-off EARLIER by the block's
+        // auxiliary workgroup, so they do not hold the wave up), which go to smu for the lanes that publish: no dependent
+        // load of q_t behind the product (that cost 0.2 us per block when the publishing lanes fetched it themselves).
+        const bool qlane = t >= 2 && lane >= 32 && lane < 56;
+        if (lane < 24 || qlane) {
             bool ok = true;
             const int j = w + 8 * (lane / 3), q = lane % 3;
-            wsm[lane] = poll_value<true>(p.mu_new + 192 * (size_t)(t - 1) + 64 * q + j, p.flags, ok);
+            const double *src = qlane ? p.q_pub + 192 * (size_t)t + 24 * w + (lane - 32)
+                                      : p.mu_new + 192 * (size_t)(t - 1) + 64 * q + j;
+            const double v = poll_value<true>(src, p.flags, ok);
+            if (qlane)
+                smu[24 * w + (lane - 32)] = v;
+            else
+                wsm[lane] = v;
             if (!ok) s_ok = 0;
         }
         GS_STAMP(8);
-        // q_t (published about one hand-off earlier by the auxiliary workgroup): requested now by the lanes that will
-        // publish, looked at behind the product
-        unsigned long long qa = 0ull, qb = 0ull;
-        if (t >= 2 && tid < 96) {
-            const unsigned long long *qp = reinterpret_cast<const unsigned long long *>(p.q_pub) + 192 * (size_t)t + 2 * tid;
-            qa = ld_agent_u64(qp);
-            qb = ld_agent_u64(qp + 1);
-        }
         if (p.ablate & 8) {  // republish what was polled (+1), nothing else
             if (lane < 24) {
                 const int j = w + 8 * (lane / 3), q = lane % 3;
@@ -716,15 +809,6 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
         zred[(w * 3 + 0) * 64 + lane] = cx;  // (over the staged hand-off, which this wave has read)
         zred[(w * 3 + 1) * 64 + lane] = cy;
         zred[(w * 3 + 2) * 64 + lane] = cz;
-        if (t >= 2 && tid < 96) {
-            bool ok = true;
-            double q0 = __longlong_as_double((long long)qa), q1 = __longlong_as_double((long long)qb);
-            if (qa == kGsSentinel) q0 = poll_value<true>(p.q_pub + 192 * (size_t)t + 2 * tid, p.flags, ok);
-            if (qb == kGsSentinel) q1 = poll_value<true>(p.q_pub + 192 * (size_t)t + 2 * tid + 1, p.flags, ok);
-            if (!ok) s_ok = 0;
-            wt.x -= q0;
-            wt.y -= q1;
-        }
         __syncthreads();
         if (!s_ok) return;
         GS_STAMP(9);
@@ -733,6 +817,11 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
     if (tid < 96) {
         const int e = 2 * tid;
         double2 mu = wt;
+        if (t >= 2) {  // q_t = Q_t mu_{t-2}, staged in smu by the polling lanes
+            const double2 qt = *reinterpret_cast<const double2 *>(smu + e);
+            mu.x -= qt.x;
+            mu.y -= qt.y;
+        }
         if (t >= 1) {
             const int q = e >> 6, i = e & 63;
             double2 acc = make_double2(0.0, 0.0);

@@ -24,13 +24,16 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert d["dtype"] == "f64" and d["vs_baseline"] is None and d["value"] > 10.0
     assert "workload" in d["config"] and "model" not in d["config"]
     rf = d["roofline"]
-    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert rf["bound"].startswith("hbm") and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0.2 < rf["frac"] < 1.0
     assert rf["launches"] >= 4 and rf["launches"] % 4 == 0  # Jacobi x4 per step of the separate probe pass, HIP events
     assert rf["avg_launch_ms"] > 0 and "incremental (bit-identical to full)" in d["config"]["workload"]
     assert d["config"]["rccl_ranks"] == 1 and d["full_rebuild_steps_per_s"] > 10.0
     for k in ("pair_rd_es_kernel", "static_field_kernel"):
         assert d["valu_kernels"][k]["pairs_per_s"] > 1e9
+    # the counters that would silently change what the line measures: a dedicated box shows 0 / 0
+    assert d["resident_fallbacks"] == 0 and d["spec_rank_redos"] == 0
+    assert len(d["ranks"]) == 1 and d["ranks"][0]["rank"] == 0 and d["ranks"][0]["steps_per_s"] > 10.0
 
 
 def test_bench_under_a_launcher_pools_through_the_c_abi_collective_with_one_rank():
