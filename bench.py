@@ -191,6 +191,15 @@ def load_workload(name):
                      feynman_hibbs=1, feynman_hibbs_order=4)
         label = "PCN-61 cell + 416 BSSP H2, 4096 atoms (2016 frozen), polarizable, Jacobi x4, rc 8 A, FH4"
         return s, flags, label
+    if name == "pcn61_21183":
+        # the reference's GPU sample in full: sample_configs_gpu/3_PCN61/{iter.inp, input.pdb} (tests/data/pcn61_full)
+        from mpmc_amd import pqr
+
+        s = pqr.read_pqr(os.path.join(ROOT, "tests", "data", "pcn61_full", "input.pdb.gz"),
+                         np.diag([128.388, 42.796, 42.796]))
+        flags = dict(temperature=77.0, polarization=1, polar_damp=2.1304, polar_max_iter=4, pbc_cutoff=8.0,
+                     feynman_hibbs=1, feynman_hibbs_order=4)
+        return s, flags, "PCN-61 3x1x1 + 3027 BSSP H2, 21183 atoms (6048 frozen), polarizable, Jacobi x4, rc 8 A, FH4"
     kind, n = name.rsplit("_", 1)
     n = int(n)
     if kind == "spol":
@@ -548,7 +557,16 @@ def main():
         # algorithmic bytes of one sweep launch (pair_sweep_kernel): one {c3, c5} coefficient pair (16 B, fp64)
         # per unordered pair of polarizable sites, read once, + coordinates and dipoles in, field out.
         # (sites with alpha = 0 carry no dipole, so neither their rows nor their columns exist)
-        n_pol = int(np.count_nonzero(np.asarray(system["alpha"]) != 0.0))
+        n_pol_initial = int(np.count_nonzero(np.asarray(system["alpha"]) != 0.0))
+        n_pol, n_final = n_pol_initial, n
+        if args.uvt:
+            # a grand-canonical chain changes its own size: the sweep that was timed ran over the configuration the chain
+            # had reached by then (at 70 atm the PCN-61 cell takes up ~15 % more H2 than it starts with), so its bytes are
+            # counted on THAT many polarizable sites -- pricing it at the initial count made the same kernel look 18 %
+            # slower under uvt than under nvt (round 2: 19.4 vs 16.4 us "on the same atoms", which they were not)
+            fin = chain.system(system["basis"])
+            n_final = len(fin["charge"])
+            n_pol = int(np.count_nonzero(fin["alpha"] != 0.0))
         m3 = 3.0 * n_pol
         gs = bool(flags.get("polar_gs") or flags.get("polar_gs_ranked"))
         expanded = (args.expanded_matrix or args.full_sweep) and not gs
@@ -636,7 +654,8 @@ def main():
             "config": {"workload": label + (" [UVT: insert/remove/displace]" if args.uvt else "") +
                                    ("; energy() rebuilt from scratch every step" if args.full_rebuild else
                                     "; energy() incremental (bit-identical to full)"),
-                       "n_atoms": n, "n_polarizable": n_pol, "walkers": world * W, "corrtime": args.corrtime,
+                       "n_atoms": n, "n_polarizable": n_pol_initial, "n_atoms_final": n_final,
+                       "n_polarizable_final": n_pol, "walkers": world * W, "corrtime": args.corrtime,
                        "parallelism": "%d independent walkers, %d per GPU" % (world * W, W),
                        "collective": collective,
                        "rccl_ranks": rccl_ranks},

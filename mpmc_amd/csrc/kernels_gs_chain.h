@@ -187,6 +187,12 @@ __device__ __forceinline__ double poll_value(const double *p, unsigned *flags, b
     return 0.0;
 }
 
+// A workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding GLOBAL load of the
+// wave (its fence drains vmcnt), which would stall the first blocks of a sweep on the 288 KB of P_t they have just
+// requested and do not need until mu_{t-1} arrives.  Used between the request of P_t and its first use, where the
+// barriers separate LDS writes from LDS reads and nothing else.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // diagnostic time stamp (100 MHz constant clock, comparable across CUs); thread 0 of the workgroup only
 #define GS_STAMP(slot)                                                                       \
     do {                                                                                     \
@@ -679,7 +685,7 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
         f_es = zred[384 + tid];
         f_yu = zred[576 + tid];
     }
-    __syncthreads();  // (everybody is done with zred: source coordinates at its head, the parked operands behind them)
+    lds_barrier();  // (everybody is done with zred: source coordinates at its head, the parked operands behind them)
     // the sums go back to "lane = target atom" on their way to the cross-wave sum (this wave's own rows of zred)
     {
         const int jl = (lane + 8 * (w + ns)) & 63;
@@ -687,7 +693,7 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
         zred[(w * 3 + 1) * 64 + jl] = ay;
         zred[(w * 3 + 2) * 64 + jl] = az;
     }
-    __syncthreads();
+    lds_barrier();
     if (!s_ok) return;
     GS_STAMP(6);
 
@@ -700,7 +706,7 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
         for (int g = 0; g < kChainWaves; ++g) sum += zred[(g * 3 + w) * 64 + lane];
         smu[w * 64 + lane] = f_al * (f_es + (f_yu - sum));  // v = D (e + yU - sum)
     }
-    __syncthreads();
+    lds_barrier();
     // M_t v: wave w takes the column groups g = w, w + 8, w + 16, w + 24 of the folded inverse.  A lane holds ONE 3 x 3
     // entry per group: of (row lane, column g) if lane > g [role 1], else of (row 63 - lane, column 62 - g) [role 2].  The
     // vector it multiplies is fetched with a per-lane LDS address (two distinct addresses per wave instruction), the
@@ -742,7 +748,7 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
         zred[(w * 3 + 1) * 64 + lane] = a1y;
         zred[(w * 3 + 2) * 64 + lane] = a1z;
     }
-    __syncthreads();
+    lds_barrier();
     // w_t: 96 lanes, two adjacent elements of the planar block vector each (same component q, atoms i, i + 1), in the
     // registers of the lanes that will publish
     double2 wt = make_double2(0.0, 0.0);
@@ -757,7 +763,7 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
             wt.y += z.y;
         }
     }
-    __syncthreads();  // zred is free again: every wave stages its share of the hand-off in its own rows below
+    lds_barrier();  // zred is free again: every wave stages its share of the hand-off in its own rows below
     GS_STAMP(7);
 
     // ---- the critical path: mu_{t-1} -> P_t mu_{t-1} -> cross-wave sum -> publish.  One barrier.
