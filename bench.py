@@ -62,6 +62,9 @@ def parse_args(argv=None):
     ap.add_argument("--corrtime", type=int, default=10)
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0,
+                    help="seconds of single-core CPU work for the cpu_baseline sample (20 for the headline; the per-size "
+                         "lines of profiles/round3_profile.sh use 8)")
     ap.add_argument("--cpu-all-cores", type=int, default=1,
                     help="also time one CPU walker per core on all cores (0 = skip)")
     ap.add_argument("--walkers-per-gpu", type=int, default=1,
@@ -694,7 +697,7 @@ def main():
             "walker_averages": avg.summary(),
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.workload, all_cores=bool(args.cpu_all_cores))
+            out["cpu_baseline"] = cpu_baseline(args.workload, budget_s=args.cpu_budget, all_cores=bool(args.cpu_all_cores))
         print(json.dumps(out))
     if identical:
         sys.stderr.write("bench.py: walkers with IDENTICAL averages %s -- the ranks ran the same chain (seed + rank not "

@@ -2,7 +2,8 @@
 driver executable `mpmc_hip` -> reference-format energy_output.
 
   * tests/data/socmof: the 1228-atom In-soc-MOF + BSSP H2 run of sample_configs_gpu/cuda_pol/noncuda_control; the
-    driver's step-0 line must be the reference's own (socMOF+BSSP.energy.dat:2), digit for digit.
+    driver's step-0 line must be the reference's own (socMOF+BSSP.energy.dat:2): rd and polarization digit for digit,
+    the Ewald column (and with it the total) to one unit of the last printed digit.
   * tests/data/pcn61_full: sample_configs_gpu/3_PCN61 in full -- 21 183 atoms (15 129 polarizable), `ensemble uvt`,
     4 steps as iter.inp asks.  The reference holds no output for it, so parity at this size is carried by what does
     not depend on size: the two non-polarization terms against the oracle (no O(N^2) memory needed there), every term
@@ -34,7 +35,15 @@ def test_driver_reproduces_the_reference_step0_line_from_its_own_pdb():
     assert r.returncode == 0, r.stdout + r.stderr
     lines = open(out).read().splitlines()
     assert lines[0].startswith("#step #energy #coulombic #rd #polar")
-    assert lines[1].split()[:5] == SOCMOF_LINE
+    got = lines[1].split()[:5]
+    # The reference's printed digits (%f).  The Ewald column is a difference of parts of +-1e7 K (real-space sum vs point
+    # self term), so one unit of the sixth decimal is 1e-13 of what is being added: the device adds its tile partials in
+    # another order than the reference's pair loop and may round the last printed digit the other way (the CPU oracle,
+    # which keeps the reference's order, prints the line exactly: tests/test_reference_inputs.py).
+    assert got[0] == "0"
+    for g, w in zip(got[1:], SOCMOF_LINE[1:]):
+        assert abs(float(g) - float(w)) <= 1.0000001e-6, (g, w)
+    assert got[3] == SOCMOF_LINE[3] and got[4] == SOCMOF_LINE[4]  # rd and polarization: every digit
     assert lines[1].split()[8] == "156.000000"  # N: the movable molecules
     assert [l.split()[0] for l in lines[1:]] == ["0", "10", "20"]
 
