@@ -206,7 +206,9 @@ struct mpmc_hip_ctx {
     int opt_res_side = 0;                  // "resident_side": 1 = feed the LJ/Ewald stream BEFORE the resident launch
     int opt_res_fold = 16;                 // "resident_fold": views of up to this many blocks run the solve without finisher
                                            // workgroups (jacobi_folded_kernel); 0 = always with finishers
-    bool resident_off = false;             // a resident launch gave up once: this context stays on the multi-launch path
+    bool resident_off = false;             // a resident launch gave up: this context keeps to the multi-launch path ...
+    long resident_retry_at = 0;            // ... until this many energy() calls have been made (then it tries once more),
+    long resident_backoff = 0;             // the interval doubling with every further give-up (4 096 ... 1 048 576 calls)
     bool call_resident = false;            // the call in flight used the resident kernel
     bool force_multi_launch = false;       // while energy_end() repeats such a call
     bool res_attr_set = false;
@@ -263,6 +265,7 @@ struct mpmc_hip_ctx {
     int n_valid = 0;                     // atoms actually present
     int next_mol = 0;                    // next unused molecule id
     std::vector<char> slot_valid;        // per atom slot
+    std::vector<char> slot_polar;        // per atom slot: polarizability != 0 (what a stated sweep order must cover exactly)
     std::vector<std::pair<int, int>> holes;  // (first, count) of removed molecules, reusable by an insert of that size
     std::vector<int> lrc_dirty_atoms;    // atoms inserted / removed since the long-range correction was summed
     // ---- one MC step as a HIP graph (see graph_step())
@@ -905,6 +908,8 @@ extern "C" int mpmc_hip_upload(mpmc_hip_ctx *c, int n, const double *x, const do
     c->n_valid = n;
     c->next_mol = m + 1;
     c->slot_valid.assign(n, 1);
+    c->slot_polar.assign(n, 0);
+    for (int i = 0; i < n; ++i) c->slot_polar[i] = (polarizability[i] != 0.0);
     c->holes.clear();
     c->lrc_dirty_atoms.clear();
     c->self_valid = false;
@@ -1132,6 +1137,7 @@ extern "C" int mpmc_hip_remove_molecule(mpmc_hip_ctx *c, int first, int count) {
         ed.mol[i] = -2 - (first + i);
         ed.flags[i] = 0;
         c->slot_valid[first + i] = 0;
+        c->slot_polar[first + i] = 0;
     }
     if (launch_edits(c, ed)) return -1;
     c->holes.push_back(std::make_pair(first, count));
@@ -1180,6 +1186,7 @@ extern "C" int mpmc_hip_insert_molecule(mpmc_hip_ctx *c, int count, const double
     else {
         c->n += count;
         c->slot_valid.resize(c->n, 0);
+        c->slot_polar.resize(c->n, 0);
         v0.slot_of_atom.resize(c->n, -1);
         const int npad = round_up(c->n, 128);
         if (npad != c->npad) {  // the tile grids of the pair / field / LRC partials change shape
@@ -1216,6 +1223,7 @@ extern "C" int mpmc_hip_insert_molecule(mpmc_hip_ctx *c, int count, const double
         ed.sig[i] = sigma[i];
         ed.molmass[i] = mm;
         c->slot_valid[a] = 1;
+        c->slot_polar[a] = (polarizability[i] != 0.0);
     }
     const int nvpad = std::max(128, round_up(v0.nv, 128));
     if (nvpad != v0.nvpad) {
@@ -1247,7 +1255,15 @@ extern "C" int mpmc_hip_set_sweep_order(mpmc_hip_ctx *c, int count, const int *s
         const int a = slots[k];
         if (a < 0 || a >= c->n || !c->slot_valid[a] || seen[a])
             return fail("MPMC_HIP: set_sweep_order: entry %d (slot %d) is not a distinct atom of the configuration", k, a);
+        if (!c->slot_polar[a])
+            return fail("MPMC_HIP: set_sweep_order: entry %d (slot %d) is not a polarizable site", k, a);
         seen[a] = 1;
+    }
+    {   // ... and EVERY polarizable site: a Gauss-Seidel sweep over a subset is a different (silently wrong) energy
+        int npolar = 0;
+        for (int a = 0; a < c->n; ++a) npolar += (c->slot_valid[a] && c->slot_polar[a]);
+        if (count != npolar)
+            return fail("MPMC_HIP: set_sweep_order: %d slots stated, the configuration has %d polarizable sites", count, npolar);
     }
     HIPCHK(hipSetDevice(c->device));
     if (flush_moves(c)) return -1;  // queued moves were addressed through the old view
@@ -2067,6 +2083,8 @@ extern "C" int mpmc_hip_energy_begin(mpmc_hip_ctx *c) {
         return fail("MPMC_HIP: energy: Gauss-Seidel after insert_molecule / remove_molecule needs the sweep order of the "
                     "new configuration (mpmc_hip_set_sweep_order)");
     HIPCHK(hipSetDevice(c->device));
+    if (c->resident_off && c->resident_backoff > 0 && (long)c->energy_calls >= c->resident_retry_at)
+        c->resident_off = false;  // (one more attempt at the one-launch solve; a give-up doubles the interval)
     const mpmc_hip_params &P = c->par;
     c->ewald_alpha = P.ewald_alpha_set ? P.ewald_alpha : 3.5 / c->cutoff;                    // pbc.c:73-74
     c->polar_ewald_alpha = P.polar_ewald_alpha_set ? P.polar_ewald_alpha : 3.5 / c->cutoff;  // pbc.c:75-76
@@ -2195,6 +2213,10 @@ extern "C" int mpmc_hip_energy_end(mpmc_hip_ctx *c, mpmc_hip_result *out) {
         // before the resident kernel could ever run again.
         ++c->resident_fallbacks;
         c->resident_off = true;
+        // a shared device may be free again later: one more attempt after `backoff` clean calls (a failed attempt costs
+        // the bounded waits, ~0.2 s, so the interval doubles every time it fails)
+        c->resident_backoff = c->resident_backoff ? std::min(2 * c->resident_backoff, 1L << 20) : 4096;
+        c->resident_retry_at = (long)c->energy_calls + c->resident_backoff;
         c->view[0].resP_armed = false;
         c->force_multi_launch = true;
         ++c->energy_calls;

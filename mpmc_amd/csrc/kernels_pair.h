@@ -90,41 +90,79 @@ __device__ __forceinline__ void pair_rd_es_body(const DevAtoms &a, const DevBox 
         if (threadIdx.x < kPairChannels) out[threadIdx.x] = 0.0;
         return;
     }
-    __shared__ JTile t;
+    // Both tiles in LDS: the screen runs with lane = row atom, the exact path over a COMPACTED list of (row, column) pairs.
+    __shared__ JTile t, ti_;
     __shared__ double red[kPairWaves][3];
+    __shared__ unsigned short clist[kWave * kWave];  // candidates of the tile, (row << 6) | column, in (wave, lane, column) order
+    __shared__ int wcount[kPairWaves];
     if (wv == 0) load_jtile(t, a, m, J * kWave, lane);
+    if (wv == 1) load_jtile(ti_, a, m, I * kWave, lane);
     __syncthreads();
 
     const int i = I * kWave + lane;
-    double xi, yi, zi;
-    moved_position(a, m, i, xi, yi, zi);
-    const float xif = (float)xi, yif = (float)yi, zif = (float)zi;
-    const double qi = a.q[i], epsi = a.eps[i], sigi = a.sig[i], mmi = a.molmass[i];
-    const int moli = a.mol[i], fli = a.flags[i];
     const double rc = bx.cutoff;
     const double rc2_hi = cutoff_prefilter_sq(rc);
     const double alpha = pp.ewald_alpha;
-
     double e_rd = 0.0, e_es = 0.0, e_intra = 0.0;
 
-    // Phase 1: flag tests + fp32 distance screen -> candidate bit per partner; phase 2: exact path for
-    // the set bits only (see static_field_kernel for why the loops are split).
+    // Phase 1 (uniform, cheap): flag tests + fp32 distance screen -> candidate bit per partner, lane = row atom, this wave's
+    // 8 of the 64 column atoms.
     unsigned long long cand = 0ull;
-    for (int jj = wv * kPairJPerWave; jj < (wv + 1) * kPairJPerWave; ++jj) {
-        const int j = J * kWave + jj;
-        const int flj = t.flags[jj];
-        // pair (i<j), both real atoms, not frozen-frozen (lj.c:193, coulombic.c:165)
-        const bool act = (j > i) && (fli & kValid) && (flj & kValid) && !((fli & kFrozen) && (flj & kFrozen));
-        // (bx.screen64 is wave-uniform: a kernel argument)
-        if (act && ((moli == t.mol[jj]) ||
-                    (bx.screen64 ? prefilter_within_d(bx, xi - t.x[jj], yi - t.y[jj], zi - t.z[jj])
-                                 : prefilter_within_f(bx, xif - t.fx[jj], yif - t.fy[jj], zif - t.fz[jj]))))
-            cand |= (1ull << jj);
+    {
+        const double xi = ti_.x[lane], yi = ti_.y[lane], zi = ti_.z[lane];
+        const float xif = ti_.fx[lane], yif = ti_.fy[lane], zif = ti_.fz[lane];
+        const int moli = ti_.mol[lane], fli = ti_.flags[lane];
+        for (int jj = wv * kPairJPerWave; jj < (wv + 1) * kPairJPerWave; ++jj) {
+            const int j = J * kWave + jj;
+            const int flj = t.flags[jj];
+            // pair (i<j), both real atoms, not frozen-frozen (lj.c:193, coulombic.c:165)
+            const bool act = (j > i) && (fli & kValid) && (flj & kValid) && !((fli & kFrozen) && (flj & kFrozen));
+            // (bx.screen64 is wave-uniform: a kernel argument)
+            if (act && ((moli == t.mol[jj]) ||
+                        (bx.screen64 ? prefilter_within_d(bx, xi - t.x[jj], yi - t.y[jj], zi - t.z[jj])
+                                     : prefilter_within_f(bx, xif - t.fx[jj], yif - t.fy[jj], zif - t.fz[jj]))))
+                cand |= (1ull << jj);
+        }
     }
-    while (cand) {
-        const int jj = __ffsll((long long)cand) - 1;
-        cand &= cand - 1ull;
-        const bool same = (moli == t.mol[jj]);
+    // Compaction (round 3): at ~3 % pair density a lane has a candidate in one step out of four, and a wave ran the exact
+    // path -- ~220 fp64 instructions with erfc / exp -- whenever ANY of its lanes had one: SQ counters of the full pass
+    // showed the vector ALU active in 22 % of the wave cycles (profiles/r03_jacobi/valu_counters.json).  The tile's
+    // candidates now go into one list, in a fixed (wave, lane, column) order, and thread k takes candidates k, k + 512, ...:
+    // every active lane of the exact path has a pair.
+    int total;
+    {
+        const int cnt = __popcll(cand);
+        int incl = cnt;  // inclusive prefix over the lanes of the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int up = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += up;
+        }
+        if (lane == 63) wcount[wv] = incl;
+        __syncthreads();
+        int base = 0;
+        total = 0;
+#pragma unroll
+        for (int k = 0; k < kPairWaves; ++k) {
+            const int ck = wcount[k];
+            if (k < wv) base += ck;
+            total += ck;
+        }
+        int pos = base + incl - cnt;
+        unsigned long long cb = cand;
+        while (cb) {
+            const int jj = __ffsll((long long)cb) - 1;
+            cb &= cb - 1ull;
+            clist[pos++] = (unsigned short)((lane << 6) | jj);
+        }
+        __syncthreads();
+    }
+    for (int idx = threadIdx.x; idx < total; idx += 64 * kPairWaves) {
+        const int ent = clist[idx];
+        const int il = ent >> 6, jj = ent & 63;
+        const double xi = ti_.x[il], yi = ti_.y[il], zi = ti_.z[il];
+        const double qi = ti_.q[il], epsi = ti_.eps[il], sigi = ti_.sig[il], mmi = ti_.mm[il];
+        const bool same = (ti_.mol[il] == t.mol[jj]);
         double r2, ri2, dx, dy, dz;
         minimum_image_sq(bx, xi - t.x[jj], yi - t.y[jj], zi - t.z[jj], r2, ri2, dx, dy, dz);
         const bool near = (ri2 <= rc2_hi);  // superset of every cutoff test below

@@ -551,7 +551,16 @@ def test_gauss_seidel_after_an_insertion_needs_and_follows_the_stated_order():
     # the caller's atom order: the new molecule sits in front of molecule 7 (atoms 35..39)
     order_atoms = np.r_[np.arange(0, 35), np.arange(320, 325), np.arange(35, 320)]
     alpha_by_slot = np.r_[s["alpha"], s["alpha"][sl]]
-    eng.set_sweep_order([a for a in order_atoms if alpha_by_slot[a] != 0.0])
+    good = [a for a in order_atoms if alpha_by_slot[a] != 0.0]
+    # the stated order must be exactly the polarizable sites: a subset, or a site without polarizability in it, would be a
+    # silently different Gauss-Seidel energy
+    with pytest.raises(engine.EngineError, match="polarizable sites"):
+        eng.set_sweep_order(good[:-1])
+    bad = list(good)
+    bad[3] = int(np.flatnonzero(alpha_by_slot == 0.0)[0])
+    with pytest.raises(engine.EngineError, match="not a polarizable site"):
+        eng.set_sweep_order(bad)
+    eng.set_sweep_order(good)
     got = eng.energy()
     s2 = {}
     for k, v in s.items():
