@@ -198,6 +198,7 @@ struct mpmc_hip_ctx {
     int opt_gs_fault_sweep = 0;
     int opt_sweep_alternate = 1;           // "sweep_alternate": pair_sweep_kernel walks each XCD's tiles forwards / backwards in turn
     int opt_sweep_ablate = 0;              // timing-only ablations of pair_sweep_kernel (wrong results)
+    int opt_sweep_split = -1;              // "sweep_split": half-tile workgroups in pair_sweep_kernel: 1 always, 0 never, -1 by size
     int opt_sweep_nt = -1;                 // "sweep_nt": non-temporal coefficient loads in pair_sweep_kernel: 1 always, 0 never,
                                            // -1 = only when the tile set cannot stay in the 256-MB Infinity Cache
     int opt_resident = 1;                  // "resident_jacobi": fixed-count Jacobi-type solves as one launch, tiles in registers
@@ -548,6 +549,8 @@ extern "C" int mpmc_hip_set_option(mpmc_hip_ctx *c, const char *name, int value)
         c->opt_fuse_moves = value;  // 0: apply_moves_kernel + update_coef_kernel as two launches (A/B; bit-identical)
     else if (!strcmp(name, "resident_fault"))
         c->opt_res_fault = value;  // test hook: the next resident launch loses a hand-off (-> fallback)
+    else if (!strcmp(name, "sweep_split"))
+        c->opt_sweep_split = value;
     else if (!strcmp(name, "inv_stamps"))
         c->opt_inv_stamps = value;
     else if (!strcmp(name, "resident_stamps"))
@@ -1410,7 +1413,7 @@ static int ensure_coef_scratch(SweepView &v, int nt) {
     // sized for every tile the view can grow to: a grand-canonical insertion that starts a new 64-atom block must not
     // pay a hipFree + hipMalloc (a millisecond, with the device idle) in the middle of an energy() call
     const size_t ntcap = (size_t)std::max(nt, v.ntld);
-    const size_t need = 2 * (3 * (size_t)kCoefTile * ntcap) * ntcap;
+    const size_t need = 4 * (3 * (size_t)kCoefTile * ntcap) * ntcap;  // (two planes: whole-tile or half-tile workgroups)
     if (v.symcap < need) {
         if (v.Srow) hipFree(v.Srow);
         v.Srow = v.Zcol = nullptr;

@@ -389,7 +389,9 @@ constexpr int kCoefFinishGroups = 16;
 template <int MODE>
 __global__ __launch_bounds__(64 * kCoefFinishGroups) void pair_finish_kernel(int nt, const double *__restrict__ Srow,
                                                                               const double *__restrict__ Zcol,
-                                                                              CoefFinish f) {
+                                                                              CoefFinish f, size_t half_plane) {
+    // (half_plane > 0: the sweep ran as half-tile workgroups; a block has 2 nt partial sums, term u + nt in the second
+    //  plane: all first halves in the order below, then all second halves)
     const int t = blockIdx.x;
     __shared__ double part[kCoefFinishGroups][3][64];
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
@@ -414,16 +416,18 @@ __global__ __launch_bounds__(64 * kCoefFinishGroups) void pair_finish_kernel(int
     }
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
     // four terms per trip, loads issued together (a term's address does not depend on data)
-    for (int u0 = g; u0 < nt; u0 += 4 * kCoefFinishGroups) {
+    const int nterm = half_plane ? 2 * nt : nt;
+    for (int u0 = g; u0 < nterm; u0 += 4 * kCoefFinishGroups) {
         double v[4][3];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int u = u0 + k * kCoefFinishGroups;
-            const bool on = u < nt;
-            const int uu = on ? u : g;
+            const bool on = u < nterm;
+            const int ux = on ? u : g;
+            const int uu = ux >= nt ? ux - nt : ux;
             // u < nt - t: row partial of tile (t, t + u); otherwise column partial of tile (u - (nt - t), t)
             const double *p = (uu < nt - t) ? Srow + (size_t)(t + uu) * ncol : Zcol + (size_t)(uu - (nt - t)) * ncol;
-            p += 192 * t + lane;
+            p += 192 * t + lane + (ux >= nt ? half_plane : 0);
             v[k][0] = on ? p[0] : 0.0;
             v[k][1] = on ? p[64] : 0.0;
             v[k][2] = on ? p[128] : 0.0;
@@ -456,15 +460,17 @@ __global__ __launch_bounds__(64 * kCoefFinishGroups) void pair_finish_kernel(int
 // their column atom one lane per step.  Shared by pair_sweep_kernel and the resident solver (kernels_resident.h), which
 // must agree to the bit: every product / sum is an explicit fma or a lone multiplication.
 // (PREMUL: c[k].y already holds -3 c5 -- the resident solver multiplies once when it loads a tile; same product, same bits)
-template <int ORTHO, int TIGHT = 0, int PREMUL = 0>
-__device__ __forceinline__ void tile_quarter_product(const double2 (&c)[kCoefSteps], int l, int w, double xi, double yi,
-                                                     double zi, double mix, double miy, double miz, const double2 *jxy,
-                                                     const double2 *jzm, const double2 *jmm, const DevBox &bx, double &sx,
-                                                     double &sy, double &sz, double &zx, double &zy, double &zz) {
+// (STEPS consecutive steps from `base`: a quarter of a tile, base = 16 w, for the whole-tile workgroups and the resident
+//  solver; an eighth, base = 32 h + 8 w, for the half-tile workgroups of pair_sweep_kernel<.., SPLIT = 1>)
+template <int ORTHO, int TIGHT, int PREMUL, int STEPS>
+__device__ __forceinline__ void tile_part_product(const double2 (&c)[STEPS], int l, int base, double xi, double yi,
+                                                  double zi, double mix, double miy, double miz, const double2 *jxy,
+                                                  const double2 *jzm, const double2 *jmm, const DevBox &bx, double &sx,
+                                                  double &sy, double &sz, double &zx, double &zy, double &zz) {
     sx = sy = sz = zx = zy = zz = 0.0;
 #pragma unroll
-    for (int k = 0; k < kCoefSteps; ++k) {
-        const int jj = (l + kCoefSteps * w + k) & 63;
+    for (int k = 0; k < STEPS; ++k) {
+        const int jj = (l + base + k) & 63;
         const double2 pa = jxy[jj], pb = jzm[jj], pm = jmm[jj];
         double dx, dy, dz;
         image_displacement<ORTHO>(bx, xi - pa.x, yi - pa.y, zi - pb.x, dx, dy, dz);
@@ -489,27 +495,46 @@ __device__ __forceinline__ void tile_quarter_product(const double2 (&c)[kCoefSte
         if (TIGHT) __builtin_amdgcn_sched_barrier(0);
     }
 }
+template <int ORTHO, int TIGHT = 0, int PREMUL = 0>
+__device__ __forceinline__ void tile_quarter_product(const double2 (&c)[kCoefSteps], int l, int w, double xi, double yi,
+                                                     double zi, double mix, double miy, double miz, const double2 *jxy,
+                                                     const double2 *jzm, const double2 *jmm, const DevBox &bx, double &sx,
+                                                     double &sy, double &sz, double &zx, double &zy, double &zz) {
+    tile_part_product<ORTHO, TIGHT, PREMUL, kCoefSteps>(c, l, kCoefSteps * w, xi, yi, zi, mix, miy, miz, jxy, jzm, jmm, bx, sx, sy,
+                                                        sz, zx, zy, zz);
+}
 
 
 // (NT: non-temporal coefficient loads; 0 = default cache policy, which lets the tiles stay in the 256-MB Infinity Cache
 //  between the sweeps of a solve and between MC steps when the whole set fits)
 // (ABLATE, timing only -- results are wrong: 1 = the tile is loaded but not multiplied, 2 = multiplied but not loaded)
-template <int ORTHO, int NT = 1, int ABLATE = 0>
+// (SPLIT = 1: TWO workgroups per tile, each multiplying 32 of its 64 steps (8 per wave) and writing its own row / column
+//  partial sums (a second plane of Srow / Zcol, `half_plane` doubles behind the first; pair_finish_kernel adds both).  At
+//  3-5 tiles per CU the CU that gets one tile more than the others sets the launch time; with half-tile units the same
+//  imbalance is half as large.  Option "sweep_split".)
+template <int ORTHO, int NT = 1, int ABLATE = 0, int SPLIT = 0>
 __global__ __launch_bounds__(64 * kCoefWaves) void pair_sweep_kernel(const double2 *__restrict__ C, int nt, int ntld,
                                                                        const double *__restrict__ x,
                                                                        const double *__restrict__ y,
                                                                        const double *__restrict__ z,
                                                                        const double *__restrict__ mu, DevBox bx,
                                                                        double *__restrict__ Srow,
-                                                                       double *__restrict__ Zcol, int rev) {
+                                                                       double *__restrict__ Zcol, int rev,
+                                                                       size_t half_plane) {
     // Workgroups are placed on the 8 XCDs round-robin by their index, so XCD x always multiplies the tiles x, x + 8, ...
     // With `rev` alternating from sweep to sweep it walks them forwards, then backwards: the tiles it read LAST in one
     // sweep (still in its 4-MB L2) are the ones it reads FIRST in the next.
-    int ti, tj;
+    int ti, tj, half = 0;
     {
         const int ntiles = nt * (nt + 1) / 2;
-        const int b = blockIdx.x, x = b & 7, i = b >> 3;
+        int b = blockIdx.x;
+        if (SPLIT) {  // units 8 u .. 8 u + 7 go to the 8 XCDs as before; the two halves of a tile are 8 apart: same XCD
+            half = (b >> 3) & 1;
+            b = ((b >> 4) << 3) | (b & 7);
+        }
+        const int x = b & 7, i = b >> 3;
         const int n_x = (ntiles - x + 7) >> 3;
+        if (SPLIT && i >= n_x) return;  // (the grid is rounded up to whole groups of 16 units)
         upper_tile_of(x + 8 * (rev ? n_x - 1 - i : i), nt, ti, tj);
     }
     const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -525,10 +550,12 @@ __global__ __launch_bounds__(64 * kCoefWaves) void pair_sweep_kernel(const doubl
     const int i = 64 * ti + l;
     const double xi = x[i], yi = y[i], zi = z[i];
     const double mix = mu[3 * i], miy = mu[3 * i + 1], miz = mu[3 * i + 2];
-    const double2 *tile = C + coef_tile_index(ti, tj, ntld) * (kCoefTile * kCoefTile) + (size_t)(kCoefSteps * w) * 64 + l;
-    double2 c[kCoefSteps];
+    constexpr int kSteps = SPLIT ? kCoefSteps / 2 : kCoefSteps;
+    const int base = SPLIT ? 32 * half + kSteps * w : kSteps * w;  // this wave's first step of the tile
+    const double2 *tile = C + coef_tile_index(ti, tj, ntld) * (kCoefTile * kCoefTile) + (size_t)base * 64 + l;
+    double2 c[kSteps];
 #pragma unroll
-    for (int k = 0; k < kCoefSteps; ++k) {
+    for (int k = 0; k < kSteps; ++k) {
         if (ABLATE == 2) c[k] = make_double2(xi + k, yi - k);
         else c[k] = NT ? stream_load_coef(tile + 64 * k) : tile[64 * k];
     }
@@ -537,34 +564,35 @@ __global__ __launch_bounds__(64 * kCoefWaves) void pair_sweep_kernel(const doubl
     if constexpr (ABLATE == 1) {
         sx = sy = sz = zx = zy = zz = 0.0;
 #pragma unroll
-        for (int k = 0; k < kCoefSteps; ++k) {
+        for (int k = 0; k < kSteps; ++k) {
             sx += c[k].x;
             zx += c[k].y;
         }
     } else {
-        tile_quarter_product<ORTHO>(c, l, w, xi, yi, zi, mix, miy, miz, jxy, jzm, jmm, bx, sx, sy, sz, zx, zy, zz);
+        tile_part_product<ORTHO, 0, 0, kSteps>(c, l, base, xi, yi, zi, mix, miy, miz, jxy, jzm, jmm, bx, sx, sy, sz, zx, zy, zz);
     }
     red[w][0][l] = sx;
     red[w][1][l] = sy;
     red[w][2][l] = sz;
-    const int jl = (l + kCoefSteps * w + kCoefSteps - 1) & 63;  // column atom this lane ended on
+    const int jl = (l + base + kSteps - 1) & 63;  // column atom this lane ended on
     red[w][3][jl] = zx;
     red[w][4][jl] = zy;
     red[w][5][jl] = zz;
     __syncthreads();
     const size_t ncol = 3 * (size_t)kCoefTile * nt;
+    const size_t plane = SPLIT ? half * half_plane : 0;
     if (w < 3) {
         double s = 0.0;
 #pragma unroll
         for (int q = 0; q < kCoefWaves; ++q) s += red[q][w][l];
-        Srow[(size_t)tj * ncol + 192 * ti + 64 * w + l] = s;
+        Srow[plane + (size_t)tj * ncol + 192 * ti + 64 * w + l] = s;
     } else if (!diag) {
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             double s = 0.0;
 #pragma unroll
             for (int q = 0; q < kCoefWaves; ++q) s += red[q][3 + p][l];
-            Zcol[(size_t)ti * ncol + 192 * tj + 64 * p + l] = s;
+            Zcol[plane + (size_t)ti * ncol + 192 * tj + 64 * p + l] = s;
         }
     }
 }

@@ -783,6 +783,40 @@ def test_sweep_variants_agree():
 
 
 
+@pytest.mark.parametrize("n,flags", [(2560, dict(polar_max_iter=4)), (4096, dict(polar_max_iter=5, polar_palmo=1, polar_rrms=1)),
+                                     (1500, dict(polar_max_iter=3, polar_sor=1, polar_gamma=0.8))])
+def test_half_tile_sweep_workgroups_agree_with_whole_tiles(n, flags):
+    """Option sweep_split: two workgroups per coefficient tile, each with its own plane of row / column partial sums, which
+    the finish kernel adds (first halves, then second halves).  Same pairs, another association of the sums: dipoles and
+    energies to 1e-13 of the whole-tile launch, both against the oracle, through a move (odd tile counts, diagonal tiles and
+    the padding block of a ragged view included)."""
+    s = synth.s_pol(n)
+    p = dict(temperature=77.0, polarization=1, polar_damp=2.1304, feynman_hibbs=1, feynman_hibbs_order=4, **flags)
+    out = []
+    for split in (0, 1):
+        e = engine.Engine(n)
+        e.load_system(s, p)
+        e.set_option("resident_jacobi", 0)
+        e.set_option("sweep_split", split)
+        e.energy()
+        e.update_atoms(35, s["pos"][35:40] + 0.07)
+        r = e.energy()
+        r.update(e.dipoles())
+        out.append(r)
+        e.close()
+    s2 = dict(s, pos=s["pos"].copy())
+    s2["pos"][35:40] += 0.07
+    want = oracle.energy(s2, p, want_vectors=True) if n <= 2560 else None
+    for r in out:
+        if want is not None:
+            check_energies(r, want)
+            assert np.abs(r["mu"] - want["mu"]).max() <= 1e-10 * np.abs(want["mu"]).max()
+    scale = np.abs(out[0]["mu"]).max()
+    assert np.abs(out[0]["mu"] - out[1]["mu"]).max() <= 1e-13 * scale
+    assert abs(out[0]["polarization_energy"] - out[1]["polarization_energy"]) <= 1e-12 * abs(out[0]["polarization_energy"])
+    assert out[0]["polar_iterations"] == out[1]["polar_iterations"]
+
+
 RESIDENT_VARIANTS = {
     "jacobi1": dict(polar_max_iter=1),
     "jacobi4": dict(polar_max_iter=4),
