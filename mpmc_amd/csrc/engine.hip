@@ -131,8 +131,8 @@ struct SweepView {
     unsigned *gsflags = nullptr; // [8] gs_chain_kernel: ticket counter, sticky error word, breadcrumbs
     // Gauss-Seidel chain (kernels_gs_chain.h): cached inverses of the diagonal blocks and expanded sub-diagonal tiles
     double *Minv = nullptr;      // [cap/64][kMinvDoubles]
-    double *Pnb = nullptr;       // [cap/64][kPnbDoubles]: P_t = M_t D T(t,t-1)
-    double *Qnb = nullptr;       // [cap/64][kPnbDoubles]: Q_t = M_t D T(t,t-2)
+    double *Lnb[kGsMaxLag] = {nullptr, nullptr, nullptr, nullptr};  // [k-1]: [cap/64][kPnbDoubles], L(k)_t = M_t D T(t,t-k)
+    int Lnb_lags = 0;            // how many of them are allocated
     unsigned long long C_epoch = 0;   // bumped by every full build of C
     unsigned long long M_epoch = 0;   // C_epoch the chain data were last fully built under (0: never)
     unsigned long long M_call = 0;    // energy() call that last maintained them
@@ -198,6 +198,8 @@ struct mpmc_hip_ctx {
     int opt_gs_fault_sweep = 0;
     int opt_sweep_alternate = 1;           // "sweep_alternate": pair_sweep_kernel walks each XCD's tiles forwards / backwards in turn
     int opt_sweep_ablate = 0;              // timing-only ablations of pair_sweep_kernel (wrong results)
+    int opt_gs_lags = 3;                   // "gs_lags": cached neighbour matrices of the chain, 2 .. kGsMaxLag (kernels_gs_chain.h)
+    int opt_gs_fuse_moves = 1;             // "gs_fuse_moves": Gauss-Seidel modes: the move rides in the coefficient update of view 0
     int opt_sweep_split = -1;              // "sweep_split": half-tile workgroups in pair_sweep_kernel: 1 always, 0 never, -1 by size
     int opt_sweep_nt = -1;                 // "sweep_nt": non-temporal coefficient loads in pair_sweep_kernel: 1 always, 0 never,
                                            // -1 = only when the tile set cannot stay in the 256-MB Infinity Cache
@@ -549,6 +551,13 @@ extern "C" int mpmc_hip_set_option(mpmc_hip_ctx *c, const char *name, int value)
         c->opt_fuse_moves = value;  // 0: apply_moves_kernel + update_coef_kernel as two launches (A/B; bit-identical)
     else if (!strcmp(name, "resident_fault"))
         c->opt_res_fault = value;  // test hook: the next resident launch loses a hand-off (-> fallback)
+    else if (!strcmp(name, "gs_lags")) {
+        if (value < 2 || value > kGsMaxLag) return fail("mpmc_hip_set_option: gs_lags must be 2 .. %d", kGsMaxLag);
+        if (value != c->opt_gs_lags) c->view[0].M_epoch = c->view[1].M_epoch = 0;  // (the matrices of the new lags are not there)
+        c->opt_gs_lags = value;
+    }
+    else if (!strcmp(name, "gs_fuse_moves"))
+        c->opt_gs_fuse_moves = value;
     else if (!strcmp(name, "sweep_split"))
         c->opt_sweep_split = value;
     else if (!strcmp(name, "inv_stamps"))
@@ -676,14 +685,14 @@ extern "C" int mpmc_hip_create(mpmc_hip_ctx **out, int device, int max_atoms) {
         DALLOC(v.mu0, 3 * np, double);
         DALLOC(v.mu1, 3 * np, double);
         DALLOC(v.munew, 3 * np, double);
-        DALLOC(v.mupub, 2 * (3 * np + 192), double);  // mu_t of a sweep, then (offset gs_qoff) the auxiliary q_t; a spare block each
+        DALLOC(v.mupub, kGsMaxLag * (3 * np + 192), double);  // mu_t of a sweep, then (gs_qoff apart) the auxiliary lags' vectors; a spare block each
         c->gs_qoff = (int)(3 * np + 192);
         DALLOC(v.y, 3 * np, double);
         DALLOC(v.efind, 3 * np, double);
         DALLOC(v.efchg, 3 * np, double);
         DALLOC(v.rrms, np, double);
-        DALLOC(v.gsflags, 8, unsigned);
-        HIPCHK(hipMemsetAsync(v.gsflags, 0, 8 * sizeof(unsigned), c->stream));
+        DALLOC(v.gsflags, 16, unsigned);
+        HIPCHK(hipMemsetAsync(v.gsflags, 0, 16 * sizeof(unsigned), c->stream));
         DALLOC(v.energy_part, 2 * (np / 64 + 1), double);
         // slots past the last tile of a view are never written by the tiled sweep: keep them defined
         for (double *p : {v.mu0, v.mu1, v.munew, v.y, v.efind, v.efchg, v.es})
@@ -745,7 +754,7 @@ extern "C" void mpmc_hip_destroy(mpmc_hip_ctx *c) {
     for (void *p : dptrs)
         if (p) hipFree(p);
     for (SweepView &v : c->view) {
-        void *vp[] = {v.resP, v.respub, v.Srow, v.Minv, v.Pnb, v.Qnb, v.mupub, v.gsflags, v.d_idx, v.d_slot, v.px, v.py, v.pz, v.palpha, v.pflags, v.A,    v.C, v.energy_part, v.es,
+        void *vp[] = {v.resP, v.respub, v.Srow, v.Minv, v.Lnb[0], v.Lnb[1], v.Lnb[2], v.Lnb[3], v.mupub, v.gsflags, v.d_idx, v.d_slot, v.px, v.py, v.pz, v.palpha, v.pflags, v.A,    v.C, v.energy_part, v.es,
                       v.mu0,   v.mu1, v.munew, v.y, v.efind, v.efchg, v.rrms};
         for (void *p : vp)
             if (p) hipFree(p);
@@ -1448,12 +1457,14 @@ static int ensure_view_coef(mpmc_hip_ctx *c, SweepView &v, int nt, hipStream_t s
 
 // cached block inverses M_t + neighbour matrices P_t = M_t D T(t,t-1) of the Gauss-Seidel chain, sized for the view's capacity
 static int ensure_view_chain(mpmc_hip_ctx *c, SweepView &v, hipStream_t st) {
-    (void)c;
-    if (v.Minv && v.Pnb && v.Qnb) return 0;
+    if (v.Minv && v.Lnb_lags >= c->opt_gs_lags) return 0;
     const size_t nbcap = (size_t)(v.cap + 63) / 64;
+    for (; v.Lnb_lags < c->opt_gs_lags; ++v.Lnb_lags) {
+        HIPCHK(hipMalloc((void **)&v.Lnb[v.Lnb_lags], nbcap * kPnbDoubles * sizeof(double)));
+        v.M_epoch = 0;
+    }
+    if (v.Minv) return 0;
     HIPCHK(hipMalloc((void **)&v.Minv, nbcap * kMinvDoubles * sizeof(double)));
-    HIPCHK(hipMalloc((void **)&v.Pnb, nbcap * kPnbDoubles * sizeof(double)));
-    HIPCHK(hipMalloc((void **)&v.Qnb, nbcap * kPnbDoubles * sizeof(double)));
     // the folded inverse has 32 padding lanes per block that no build writes: they must read as zero
     HIPCHK(hipMemsetAsync(v.Minv, 0, nbcap * kMinvDoubles * sizeof(double), st));
     v.M_epoch = 0;
@@ -1787,8 +1798,13 @@ static int enqueue_direct(mpmc_hip_ctx *c) {
     // that update does not happen.  (Not in the Gauss-Seidel modes: their ranking kernels read the coordinates first.)
     {
         const mpmc_hip_params &Pm = c->par;
+        // (Gauss-Seidel modes, round 3: with the chain kernel's data -- whose maintenance follows the coefficient update
+        //  inside setup_view() -- the move rides in update_coef_moves_kernel too, as a launch of its own in front of the block
+        //  matrices instead of apply_moves_kernel + update_coef_kernel; the side stream, whose ranking kernels read the
+        //  coordinates, applies the same move for itself as before (side_apply).  Option "gs_fuse_moves".)
+        const bool gs = Pm.polar_gs || Pm.polar_gs_ranked;
         c->moves_deferred = c->opt_fuse_moves && c->pending.n > 0 && c->graph_mode == GM_DIRECT && !c->opt_graph &&
-                            !Pm.rd_only && Pm.polarization && !Pm.polar_zodid && !Pm.polar_gs && !Pm.polar_gs_ranked &&
+                            !Pm.rd_only && Pm.polarization && !Pm.polar_zodid && (!gs || (c->opt_gs_fuse_moves && gs_order_mode(c))) &&
                             Pm.polar_precision == 0.0 && c->opt_overlap && c->opt_pair_coef && !c->all_dirty &&
                             c->view[0].C_valid && c->view[0].pos_valid;
     }
@@ -1804,11 +1820,13 @@ static int enqueue_direct(mpmc_hip_ctx *c) {
             c->graph_mode == GM_DIRECT && !c->opt_graph)
             c->side_apply = c->pending;  // (the side stream applies it too: no fork event, see side_wait_for_moves)
         if (flush_moves(c)) return -1;
+    } else if (c->moves_deferred && (c->par.polar_gs || c->par.polar_gs_ranked)) {
+        if (c->opt_side_moves && !c->main_writes) c->side_apply = c->pending;  // (else: the fork event behind the coefficient job)
     }
     // (the pair kernel is launched whenever an atom moved; the long-range-correction kernels in front of it read
     //  parameters only)
-    c->side_carry = c->moves_deferred && c->opt_side_moves && !c->main_writes && !c->dirty_atoms.empty() &&
-                    c->pending.n <= kMaxMoves;
+    c->side_carry = c->moves_deferred && !(c->par.polar_gs || c->par.polar_gs_ranked) && c->opt_side_moves && !c->main_writes &&
+                    !c->dirty_atoms.empty() && c->pending.n <= kMaxMoves;
     c->side_moves.n = 0;
     if (is_timed_call(c)) hipEventRecord(c->ev_first, c->stream);
 

@@ -29,6 +29,7 @@
 
 namespace mpmc {
 
+constexpr int kGsArmRegions = 4;  // hand-off regions of the Gauss-Seidel chain: mu_t + one per auxiliary lag (kGsMaxLag)
 constexpr int kCoefTile = 64;        // atoms per tile edge (= one wave)
 constexpr int kCoefWaves = 4;        // waves per sweep workgroup; each takes 64/4 = 16 steps of a tile
 constexpr int kCoefSteps = kCoefTile / kCoefWaves;
@@ -621,8 +622,10 @@ __global__ __launch_bounds__(64 * kCoefWaves) void pair_upper_kernel(const doubl
     //  the ticket counter; the error word, gsflags[1], is sticky for the whole energy() call and is NOT touched)
     if (arm_nb > 0) {
         if ((int)blockIdx.x < arm_nb && threadIdx.x < 192) {
-            mu_new[192 * blockIdx.x + threadIdx.x] = __longlong_as_double(0x7ff8dead7ff8deadll);
-            mu_new[arm_qoff + 192 * blockIdx.x + threadIdx.x] = __longlong_as_double(0x7ff8dead7ff8deadll);  // q_t (aux workgroups)
+            // mu_t, then one region per auxiliary lag (q_t, ...), arm_qoff doubles apart
+#pragma unroll
+            for (int r = 0; r < kGsArmRegions; ++r)
+                mu_new[r * (size_t)arm_qoff + 192 * blockIdx.x + threadIdx.x] = __longlong_as_double(0x7ff8dead7ff8deadll);
         }
         if (blockIdx.x == 0 && threadIdx.x == 0) gsflags[0] = 0u;
     }
@@ -689,10 +692,11 @@ __global__ __launch_bounds__(64 * kCoefFinishGroups) void pair_upper_finish_kern
                 // (gsflags[1]) is sticky for the whole energy() call and is NOT touched here
         const double sentinel = __longlong_as_double(0x7ff8dead7ff8deadll);
         if (threadIdx.x < 192) {
-            mu_new[192 * t + threadIdx.x] = sentinel;
-            mu_new[arm_qoff + 192 * t + threadIdx.x] = sentinel;  // q_t (the chain's auxiliary workgroups)
+            // mu_t, then one region per auxiliary lag of the chain (q_t, ...), arm_qoff doubles apart
+#pragma unroll
+            for (int r = 0; r < kGsArmRegions; ++r) mu_new[r * (size_t)arm_qoff + 192 * t + threadIdx.x] = sentinel;
         }
-        if (t == 0 && threadIdx.x == 0) gsflags[0] = 0u;
+        if (t == 0 && threadIdx.x == 0) gsflags[0] = 0u;  // the ticket counter; not the sticky error word [1] nor the breadcrumbs
     }
     __shared__ double part[kCoefFinishGroups][3][64];
     const size_t ncol = 3 * (size_t)kCoefTile * nt;

@@ -30,25 +30,35 @@
 // The result is algebraically the reference's; it differs from the literal substitution by rounding only (1e-13
 // relative, tests hold 1e-10).
 //
-// Work decomposition: a MAIN workgroup per 64-atom block (8 waves) plus, for t >= 2, the auxiliary one.  A workgroup
-// draws its role from a ticket counter when it STARTS -- tickets 0, 1: main(0), main(1); then aux(t), main(t) for
-// t = 2, 3, ... -- so it only ever waits for data of workgroups with a smaller ticket, which are already running or
-// done (aux(t) waits for main(t-2), main(t) for main(s < t) and aux(t)): no co-residency assumption, no deadlock under
-// any dispatch order or oversubscription (several walkers on one GPU).  Main workgroup t
+// The same step once more (round 3, second half): with P and Q the far sources ended at t-3, and the stages that hang
+// on mu_{t-3} -- hand-off 0.5 + tile product 0.9 + sums 0.6 + M_t product 1.1 = 3.1 us -- had to fit into the TWO block
+// times between mu_{t-3} and mu_{t-1}: that tail, not the critical section, set the block period (1.55-1.9 us; stamps in
+// profiles/r03_gs/).  So the matrices of further lags k = 3 .. nlag are cached too, L(k)_t = M_t D T(t,t-k), each on an
+// auxiliary workgroup of its own, and
+//     mu_t = ((w_t - sum_{k>=3} l(k)_t) - q_t) - P_t mu_{t-1},    w_t = M_t D (e + yU - sum_{s<=t-nlag-1} T(t,s) mu_s),
+// which gives the tail nlag block times.  (Sharing the far tiles between the main and the auxiliary workgroup instead
+// -- every other source each -- was measured first: 84 us, SLOWER than 78: it does not shorten the tail and adds a
+// dependent hand-off to it.)
+//
+// Work decomposition: a MAIN workgroup per 64-atom block (8 waves) plus one auxiliary workgroup per lag k = 2 .. nlag
+// (for t >= k).  A workgroup draws its role from a ticket counter when it STARTS -- block by block: aux(t, nlag), ...,
+// aux(t, 2), main(t) -- so it only ever waits for data of workgroups with a smaller ticket, which are already running or
+// done (aux(t, k) waits for main(t-k), main(t) for main(s < t) and its own auxiliaries): no co-residency assumption, no
+// deadlock under any dispatch order or oversubscription (several walkers on one GPU).  Main workgroup t
 //   1. stages M_t in LDS (147 KB) and P_t in registers (288 KB = 72 doubles per lane of the 128 a lane has at two
 //      waves per SIMD) -- nothing on the critical path touches HBM;
-//   2. for s = 0 .. t-3, as mu_s is published: acc += T(t,s) mu_s from the 16-B pair coefficients, geometry
+//   2. for s = 0 .. t-nlag-1, as mu_s is published: acc += T(t,s) mu_s from the 16-B pair coefficients, geometry
 //      rebuilt in registers as in pair_sweep_kernel (lane = source atom, the target sums rotate across the
-//      lanes; forward and backward passes alternate so the sums end where they started); coefficients of the
-//      next tile are in flight while the current one is multiplied;
-//   3. on mu_{t-3} (the last of those sources): v = D (e + yU - acc), w''_t = M_t v from LDS;
-//   4. on mu_{t-1}: P_t mu_{t-1} from registers, cross-wave sum, publishes mu_t = (w''_t - q_t) - that.
+//      lanes, always the same way); coefficients of the next tile are in flight while the current one is multiplied;
+//   3. on the last of those sources: v = D (e + yU - acc), w_t = M_t v from LDS, minus the l(k)_t of the lags >= 3;
+//   4. on mu_{t-1}: P_t mu_{t-1} from registers, cross-wave sum, publishes mu_t = (w_t - q_t) - that.
 // Hand-offs are data-is-the-flag (Guideline 16, R2 with the value as its own tag): mu_new is pre-filled with
 // a sentinel NaN pattern, the producer writes every double with one agent-scope (sc1, write-through) 8-byte
 // store, consumers poll their own element with agent-scope loads.  Every spin is bounded; a give-up sets a
 // STICKY error word (zeroed once per energy(), never by a sweep) that mpmc_hip_energy_end() turns into an error.
 // All sums have a fixed order: results do not depend on placement or timing.
 #pragma once
+#include <type_traits>
 #include "device_common.h"
 #include "kernels_gs.h"
 #include "kernels_coef.h"  // image_displacement, wave_rotate_down, the coefficient tile layout
@@ -60,6 +70,10 @@ constexpr int kChainWaves = 8;
 constexpr int kChainThreads = 64 * kChainWaves;
 constexpr unsigned kGsSpinLimit = 1u << 22;  // ~3 s of polling; a legitimate wait is at most one sweep (< 1 ms)
 constexpr unsigned long long kGsSentinel = 0x7ff8dead7ff8deadull;  // a NaN no arithmetic produces
+#ifndef GS_POLL_VARIANT
+#define GS_POLL_VARIANT 0  // timing experiments (tools/ab builds): urgent polls 1 = one load at a time, no sleep; 2 = two in flight;
+                           // 3 = the critical section's block poll with two attempts in flight
+#endif
 
 // ---- cached block inverse M_t, "folded" so that one wave instruction is always fully used:
 //   group g (0..31), element e = 3 p + q (row component p, column component q), lane l:
@@ -81,12 +95,26 @@ __device__ __forceinline__ int minv_index(int row, int col, int e) {  // row > c
 }
 
 // ---- cached neighbour matrix P_t = M_t D T(t, t-1): target atom i (component p) of block t, source atom j
-// (component q) of block t-1, element e = 3 p + q.  Wave w of the chain kernel multiplies the sources j = w + 8 k
-// (k = 0..7); two of them (k = 2 m, 2 m + 1) share a 16-byte word so that the 72 doubles per lane arrive as 36 loads:
-//   Pnb[t * 36864 + ((((j & 7) * 4 + (j >> 4)) * 9 + e) * 64 + i) * 2 + ((j >> 3) & 1)]
+// (component q) of block t-1, element e = 3 p + q.  Wave w of the chain kernel multiplies the sources j = 8 w + k
+// (k = 0..7: EIGHT ADJACENT atoms, so that the 24 doubles of mu_{t-1} it polls are three 64-byte segments of the planar
+// hand-off buffer -- with the strided assignment j = w + 8 k of the first version every polling instruction of every
+// wave touched 24 cache lines); two of them (k = 2 m, 2 m + 1) share a 16-byte word so that the 72 doubles per lane arrive
+// as 36 loads:
+//   Pnb[t * 36864 + ((((j >> 3) * 4 + ((j & 7) >> 1)) * 9 + e) * 64 + i) * 2 + (j & 1)]
 constexpr int kPnbDoubles = 64 * 9 * 64;  // per block (294 912 B)
+constexpr int kGsMaxLag = 4;              // cached lags: P (1), Q (2), and up to two more
+static_assert(kGsMaxLag == kGsArmRegions, "one armed hand-off region per lag (region 0 = mu_t itself)");
 __device__ __forceinline__ int pnb_index(int i, int j, int e) {
-    return ((((j & 7) * 4 + (j >> 4)) * 9 + e) * 64 + i) * 2 + ((j >> 3) & 1);
+    return ((((j >> 3) * 4 + ((j & 7) >> 1)) * 9 + e) * 64 + i) * 2 + (j & 1);
+}
+
+// number of workgroups in front of block t's (= tickets before aux(t, nlag)), and of the whole chain with t = nb
+__host__ __device__ inline int gs_chain_ticket_base(int t, int nlag) {
+    // block u has 1 + min(u, nlag) - 1 ... = max(1, min(u, nlag)) workgroups
+    int n = 0;
+    for (int u = 0; u < t && u < nlag; ++u) n += (u < 1 ? 1 : u);
+    if (t > nlag) n += (t - nlag) * nlag;
+    return n;
 }
 
 struct GsChain {
@@ -94,9 +122,10 @@ struct GsChain {
     int ntld, nb;
     const double *px, *py, *pz, *alpha, *es;
     const double *Minv;
-    const double *Pnb;   // P_t = M_t D T(t,t-1)
-    const double *Qnb;   // Q_t = M_t D T(t,t-2), same layout
-    double *q_pub;       // hand-off buffer of the auxiliary workgroups: q_t = Q_t mu_{t-2}, laid out and armed like mu_new
+    const double *Lnb[kGsMaxLag];  // [k-1]: L(k)_t = M_t D T(t,t-k), k = 1 (P_t), 2 (Q_t), ... nlag; the same layout each
+    double *pub[kGsMaxLag];        // [k-1], k >= 2: hand-off buffer of the lag's auxiliary workgroups, l(k)_t = L(k)_t mu_{t-k},
+                                   // laid out and armed like mu_new ([0] unused)
+    int nlag;                      // 2 .. kGsMaxLag
     double *y;         // in: upper-triangle part (pair_upper_finish_kernel); out: E_induced at update time
     double *mu_new;    // out, PLANAR per block: mu_new[192 t + 64 q + i] = component q of atom i of block t (so that a
                        // block is published with 16-byte stores and polled with coalesced loads); pre-filled with
@@ -138,6 +167,12 @@ __device__ __forceinline__ void st_agent16(double *p, double a, double b) {
     asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
 }
 
+__device__ __forceinline__ unsigned gs_xcc_id() {  // which of the 8 XCDs this wave runs on
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 0xfu;
+}
+
 __device__ __forceinline__ void st_agent(double *p, double v) {
     __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v),
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -155,7 +190,24 @@ template <bool URGENT>
 __device__ __forceinline__ double poll_value(const double *p, unsigned *flags, bool &ok) {
     const unsigned long long *q = reinterpret_cast<const unsigned long long *>(p);
     const unsigned limit = kGsSpinLimit;
-    if (URGENT) {
+    if (URGENT && GS_POLL_VARIANT == 1) {
+        for (unsigned it = 0; it < 16 * limit; ++it) {
+            const unsigned long long v = ld_agent_u64(q);
+            if (v != kGsSentinel) return __longlong_as_double((long long)v);
+            if ((it & 1023u) == 1023u && __hip_atomic_load(flags + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        }
+    } else if (URGENT && GS_POLL_VARIANT == 2) {
+        unsigned long long v0 = ld_agent_u64(q);
+        __builtin_amdgcn_s_sleep(2);
+        unsigned long long v1 = ld_agent_u64(q);
+        for (unsigned it = 0; it < 4 * limit; ++it) {
+            if (v0 != kGsSentinel) return __longlong_as_double((long long)v0);
+            v0 = v1;
+            if ((it & 1023u) == 1023u && __hip_atomic_load(flags + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+            v1 = ld_agent_u64(q);
+            __builtin_amdgcn_s_sleep(2);
+        }
+    } else if (URGENT) {
         unsigned long long v0 = ld_agent_u64(q);
         __builtin_amdgcn_s_sleep(1);
         unsigned long long v1 = ld_agent_u64(q);
@@ -185,6 +237,48 @@ __device__ __forceinline__ double poll_value(const double *p, unsigned *flags, b
     }
     ok = false;
     return 0.0;
+}
+
+// Poll the three doubles p[0], p[64], p[128] (one lane's share of a planar block of 192) with the three loads of an
+// attempt in flight TOGETHER: one round trip per attempt for the whole block when a full wave calls this.
+__device__ __forceinline__ bool poll_three(const double *p, unsigned *flags, double &a, double &b, double &c) {
+    const unsigned long long *q = reinterpret_cast<const unsigned long long *>(p);
+#if GS_POLL_VARIANT == 3  // (timing experiment: two attempts in flight, half a round trip apart)
+    {
+        unsigned long long ua = ld_agent_u64(q), ub = ld_agent_u64(q + 64), uc = ld_agent_u64(q + 128);
+        __builtin_amdgcn_s_sleep(6);
+        for (unsigned it = 0; it < 16 * kGsSpinLimit; ++it) {
+            const unsigned long long va = ld_agent_u64(q), vb = ld_agent_u64(q + 64), vc = ld_agent_u64(q + 128);
+            if (ua != kGsSentinel && ub != kGsSentinel && uc != kGsSentinel) {
+                a = __longlong_as_double((long long)ua);
+                b = __longlong_as_double((long long)ub);
+                c = __longlong_as_double((long long)uc);
+                return true;
+            }
+            ua = va;
+            ub = vb;
+            uc = vc;
+            if ((it & 1023u) == 1023u && __hip_atomic_load(flags + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        }
+    }
+#endif
+    for (unsigned it = 0; it < 16 * kGsSpinLimit; ++it) {
+        const unsigned long long ua = ld_agent_u64(q), ub = ld_agent_u64(q + 64), uc = ld_agent_u64(q + 128);
+        if (ua != kGsSentinel && ub != kGsSentinel && uc != kGsSentinel) {
+            a = __longlong_as_double((long long)ua);
+            b = __longlong_as_double((long long)ub);
+            c = __longlong_as_double((long long)uc);
+            return true;
+        }
+        if ((it & 1023u) == 1023u && __hip_atomic_load(flags + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+    }
+    if (__hip_atomic_exchange(flags + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        flags[2] = blockIdx.x;
+        flags[3] = threadIdx.x;
+        flags[4] = (unsigned)(reinterpret_cast<unsigned long long>(p) & 0xffffffffu);
+    }
+    a = b = c = 0.0;
+    return false;
 }
 
 // A workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding GLOBAL load of the
@@ -249,28 +343,37 @@ struct BlockList {
 // x_b = -alpha_b r_b leaves lane b through SGPRs (v_readlane, no LDS crossbar, no reduction) and every lane a > b
 // adds T_ab x_b.  The block's tensors are expanded once into LDS from the diagonal coefficient tile (packed by
 // column: rows a > b of column b are contiguous, 6 doubles per pair).
-// grid = (192 / WAVES, blocks, 3); block = 64 WAVES; dynamic LDS = kInverseLds.
-// z-slice 0: M_t of block t = sel.blk[blockIdx.y] (sel.n = 0: t = blockIdx.y, every block of the view);
-// z-slice 1: P_t = M_t D T(t,t-1) of block t = nbt.blk[blockIdx.y] (nbt.n = 0: every block t >= 1): the same forward
-//   substitution with the right-hand side D T(t,t-1)[:, (j, q)] -- wave's scalar column = source atom j of block t-1,
-//   component q -- so x_b = rhs_b - alpha_b r_b at every step and all 64 lanes carry a value from b = 0 on.
-// z-slice 2: Q_t = M_t D T(t,t-2) of block t = nbq.blk[blockIdx.y] (nbq.n = 0: every block t >= 2): the same with the
-//   tile two blocks back.
-// A workgroup whose blockIdx.y is beyond its slice's list returns at once (grid.y = the longest list).
+// grid = (192 / WAVES, blocks, 2 + nlag); block = 64 WAVES; dynamic LDS = kInverseLds.
+// z-slice 0: M_t of block t = inv.blk[blockIdx.y];
+// z-slice 1: L(k)_t = M_t D T(t,t-k) for EVERY lag k = 1 .. min(t, nlag) of block t = own.blk[blockIdx.y] (a block whose
+//   own atoms changed): the same forward substitution with the right-hand sides D T(t,t-k)[:, (j, q)] -- wave's scalar
+//   column = source atom j of block t-k, component q -- so x_b = rhs_b - alpha_b r_b at every step and all 64 lanes carry
+//   a value from b = 0 on; the nlag right-hand sides of a wave share the tensor fetches of a step and interleave their
+//   dependent chains (a pass of three costs about what a pass of one does);
+// z-slice 1 + k: L(k)_t alone of block t = nb[k-1].blk[blockIdx.y] (the block k places behind a changed one).
+// A workgroup whose blockIdx.y is beyond its slice's list returns at once (grid.y = the longest list).  nb_all > 0:
+// every block of the view, slices 0 and 1 only.
 // ---------------------------------------------------------------------------------------------
 constexpr int kInverseLds = (kGsPairs * 6 + 8 + 4 * 64) * 8;  // tensors + one all-zero pair (padded to 64 B) + x, y, z, alpha
 // Two geometries (WAVES waves per workgroup, 192 / WAVES workgroups per block): 4 waves x 48 workgroups finishes a
 // couple of blocks soonest (17.5 vs 24 us: the moved atoms' blocks of view 0 are on the step's critical path), 16 waves
 // x 12 workgroups repeats the tile expansion a quarter as often and rebuilds a whole view 3.6x faster (46 vs 166 us).
+struct GsBuild {
+    BlockList inv;             // z-slice 0: M_t of these blocks
+    BlockList own;             // z-slice 1: every L(k)_t, k = 1 .. min(t, nlag), of these blocks (their M_t changed), ONE pass
+    BlockList nb[kGsMaxLag];   // z-slice 1 + k: L(k)_t alone (the tile (t-k, t) changed: t = a changed block + k)
+    double *Minv;
+    double *Lnb[kGsMaxLag];
+    int nlag;
+    int nb_all;                // > 0: every block of the view (slices 0 and 1 take blockIdx.y as the block, the others nothing)
+};
+
 template <int ORTHO, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void gs_block_inverse_kernel(const double2 *__restrict__ C, int ntld,
                                                                 const double *__restrict__ px,
                                                                 const double *__restrict__ py,
                                                                 const double *__restrict__ pz,
-                                                                const double *__restrict__ alpha, DevBox bx, BlockList sel,
-                                                                double *__restrict__ Minv, BlockList nbt,
-                                                                double *__restrict__ Pnb, BlockList nbq,
-                                                                double *__restrict__ Qnb, int nb,
+                                                                const double *__restrict__ alpha, DevBox bx, GsBuild g,
                                                                 unsigned long long *__restrict__ stamps) {
     // diagnostic (option "inv_stamps"): per workgroup, s_memrealtime at start / loads landed / expanded / solved
     const int wg_ = ((int)blockIdx.z * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + (int)blockIdx.x;
@@ -279,12 +382,21 @@ __global__ __launch_bounds__(64 * WAVES) void gs_block_inverse_kernel(const doub
         if (stamps && threadIdx.x == 0) stamps[(size_t)wg_ * 4 + (k)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
     INV_STAMP(0);
-    const int back = blockIdx.z;  // 0: M_t; 1: P_t (tile t-1); 2: Q_t (tile t-2)
-    const bool pmode = back >= 1;
-    const BlockList &lst = (back == 0) ? sel : (back == 1 ? nbt : nbq);
-    if (lst.n > 0 ? (int)blockIdx.y >= lst.n : (int)blockIdx.y >= nb) return;
-    const int t = (lst.n > 0) ? lst.blk[blockIdx.y] : (int)blockIdx.y;
-    if (t < back) return;
+    const int zs = blockIdx.z;
+    const bool pmode = zs >= 1;
+    int t;
+    if (g.nb_all > 0) {
+        if (zs >= 2 || (int)blockIdx.y >= g.nb_all) return;
+        t = (int)blockIdx.y;
+    } else {
+        const BlockList &lst = (zs == 0) ? g.inv : (zs == 1 ? g.own : g.nb[zs - 2]);
+        if ((int)blockIdx.y >= lst.n) return;
+        t = lst.blk[blockIdx.y];
+    }
+    // the lags this workgroup solves: lag0 .. lag0 + nl - 1
+    const int lag0 = (zs <= 1) ? 1 : zs - 1;
+    const int nl = (zs == 0) ? 0 : (zs == 1 ? (t < g.nlag ? t : g.nlag) : (t >= lag0 ? 1 : 0));
+    if (pmode && nl < 1) return;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     // pair (a, b), a > b, at index off(b) + a - b - 1 (off(b) = 63 b - b (b - 1) / 2): 6 adjacent doubles {xx, xy, xz, yy, yz,
     // zz} = three 16-byte words, rows a of a column b contiguous; index kGsPairs = an all-zero pair, which the lanes a <= b
@@ -306,16 +418,21 @@ __global__ __launch_bounds__(64 * WAVES) void gs_block_inverse_kernel(const doub
         const int sr = 1 + w + k * WAVES;
         cfd[k] = (sr < 64 && lane + sr < 64) ? tile[sr * 64 + lane] : make_double2(0.0, 0.0);
     }
-    // (P / Q: the coefficient of the pair (lane a of block t, source atom c of block t - back) -- the tile (t - back, t)
+    // (lag k: the coefficient of the pair (lane a of block t, source atom c of block t - k) -- the tile (t - k, t)
     //  holds it as element (l = c, s = (a - c) & 63) -- and that atom's coordinates)
-    double2 cfn = make_double2(0.0, 0.0);
-    double pjx = 0.0, pjy = 0.0, pjz = 0.0;
-    if (pmode) {
-        cfn = (C + coef_tile_index(t - back, t, ntld) * (kCoefTile * kCoefTile))[((lane - c) & 63) * 64 + c];
-        const int js = 64 * (t - back) + c;
-        pjx = px[js];
-        pjy = py[js];
-        pjz = pz[js];
+    double2 cfn[kGsMaxLag];
+    double pjx[kGsMaxLag], pjy[kGsMaxLag], pjz[kGsMaxLag];
+#pragma unroll
+    for (int k = 0; k < kGsMaxLag; ++k) {
+        cfn[k] = make_double2(0.0, 0.0);
+        pjx[k] = pjy[k] = pjz[k] = 0.0;
+        if (k < nl) {
+            const int ts = t - (lag0 + k);
+            cfn[k] = (C + coef_tile_index(ts, t, ntld) * (kCoefTile * kCoefTile))[((lane - c) & 63) * 64 + c];
+            pjx[k] = px[64 * ts + c];
+            pjy[k] = py[64 * ts + c];
+            pjz[k] = pz[64 * ts + c];
+        }
     }
     if (w == 0) {
         sx[lane] = px[64 * t + lane];
@@ -344,7 +461,6 @@ __global__ __launch_bounds__(64 * WAVES) void gs_block_inverse_kernel(const doub
     __syncthreads();
     INV_STAMP(2);
     const double al = sal[lane];
-    double r0 = 0.0, r1 = 0.0, r2 = 0.0;     // lane a: sum_{c <= b < a} T_ab x_b
     // The substitution is a 63-step dependent chain per column, so a step must hold nothing but the chain itself: the
     // tensors of step b + 1 are requested from LDS BEFORE step b's arithmetic (they do not depend on it; round 2 read them,
     // and alpha_b, inside the step: two LDS round trips of ~120 cycles each per step were most of the kernel's 17-20 us),
@@ -354,42 +470,76 @@ __global__ __launch_bounds__(64 * WAVES) void gs_block_inverse_kernel(const doub
         return T6 + 6 * pidx;
     };
     if (pmode) {
-        // right-hand side of lane a: alpha_a T(a, j)[:, q], j = source atom c of block t - back (T is even in the displacement)
-        const double2 cf = cfn;
-        double dx, dy, dz;
-        image_displacement<ORTHO>(bx, pjx - sx[lane], pjy - sy[lane], pjz - sz[lane], dx, dy, dz);
-        const double dq = (q == 0) ? dx : (q == 1 ? dy : dz);
-        const double c5m = -3.0 * cf.y * dq;
-        const double h0 = al * (c5m * dx + (q == 0 ? cf.x : 0.0));
-        const double h1 = al * (c5m * dy + (q == 1 ? cf.x : 0.0));
-        const double h2 = al * (c5m * dz + (q == 2 ? cf.x : 0.0));
-        LdsTensor nx;
-        lds_tensor_request(tensor_of(0), nx);
-        for (int b = 0; b < 63; ++b) {
-            // x_b = rhs_b - alpha_b r_b of lane b (every lane forms its own candidate; lane b's is final)
-#if INV_ABLATE == 2
-            const double x0 = fma(-al, r0, h0), x1 = fma(-al, r1, h1), x2 = fma(-al, r2, h2);
-#else
-            const double x0 = readlane_f64(fma(-al, r0, h0), b);
-            const double x1 = readlane_f64(fma(-al, r1, h1), b);
-            const double x2 = readlane_f64(fma(-al, r2, h2), b);
-#endif
-            lds_tensor_wait(nx);
-            const LdsTensor tt = nx;
-            lds_tensor_request(tensor_of(b + 1 < 63 ? b + 1 : 62), nx);  // step b + 1's, behind which step b computes
-            __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise moves the request behind the arithmetic)
-            r0 = fma(tt.b.x, x2, fma(tt.a.y, x1, fma(tt.a.x, x0, r0)));
-            r1 = fma(tt.c.x, x2, fma(tt.b.y, x1, fma(tt.a.y, x0, r1)));
-            r2 = fma(tt.c.y, x2, fma(tt.c.x, x1, fma(tt.b.x, x0, r2)));
-        }
-        lds_tensor_wait(nx);  // (nothing of this wave's stays in flight)
-        double *out = (back == 1 ? Pnb : Qnb) + (size_t)t * kPnbDoubles;
-        out[pnb_index(lane, c, 0 + q)] = fma(-al, r0, h0);
-        out[pnb_index(lane, c, 3 + q)] = fma(-al, r1, h1);
-        out[pnb_index(lane, c, 6 + q)] = fma(-al, r2, h2);
+        // K right-hand sides in one pass over the block's tensors (the K chains are independent: they fill each other's
+        // latency gaps, and the tensors of a step are fetched once).  Per right-hand side the operations and their order are
+        // those of a pass of its own: same bits whether a matrix is built alone or with the block's others.
+        auto solve = [&](auto KC) {
+            constexpr int K = decltype(KC)::value;
+            double h[K][3], r[K][3];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                // right-hand side of lane a: alpha_a T(a, j)[:, q], j = source atom c of block t - lag (T is even in the displacement)
+                double dx, dy, dz;
+                image_displacement<ORTHO>(bx, pjx[k] - sx[lane], pjy[k] - sy[lane], pjz[k] - sz[lane], dx, dy, dz);
+                const double dq = (q == 0) ? dx : (q == 1 ? dy : dz);
+                const double c5m = -3.0 * cfn[k].y * dq;
+                h[k][0] = al * (c5m * dx + (q == 0 ? cfn[k].x : 0.0));
+                h[k][1] = al * (c5m * dy + (q == 1 ? cfn[k].x : 0.0));
+                h[k][2] = al * (c5m * dz + (q == 2 ? cfn[k].x : 0.0));
+                r[k][0] = r[k][1] = r[k][2] = 0.0;
+            }
+            LdsTensor nx;
+            lds_tensor_request(tensor_of(0), nx);
+            for (int b = 0; b < 63; ++b) {
+                // x_b = rhs_b - alpha_b r_b of lane b (every lane forms its own candidate; lane b's is final)
+                double x[K][3];
+#pragma unroll
+                for (int k = 0; k < K; ++k)
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) x[k][i] = readlane_f64(fma(-al, r[k][i], h[k][i]), b);
+                lds_tensor_wait(nx);
+                const LdsTensor tt = nx;
+                lds_tensor_request(tensor_of(b + 1 < 63 ? b + 1 : 62), nx);  // step b + 1's, behind which step b computes
+                __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise moves the request behind the arithmetic)
+                // (component by component, independent chains interleaved: a dependent fp64 FMA issued back to back stalls a
+                //  lone wave for its pipeline latency -- same operations in the same order per component, same bits)
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    r[k][0] = fma(tt.a.x, x[k][0], r[k][0]);
+                    r[k][1] = fma(tt.a.y, x[k][0], r[k][1]);
+                    r[k][2] = fma(tt.b.x, x[k][0], r[k][2]);
+                }
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    r[k][0] = fma(tt.a.y, x[k][1], r[k][0]);
+                    r[k][1] = fma(tt.b.y, x[k][1], r[k][1]);
+                    r[k][2] = fma(tt.c.x, x[k][1], r[k][2]);
+                }
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    r[k][0] = fma(tt.b.x, x[k][2], r[k][0]);
+                    r[k][1] = fma(tt.c.x, x[k][2], r[k][1]);
+                    r[k][2] = fma(tt.c.y, x[k][2], r[k][2]);
+                }
+            }
+            lds_tensor_wait(nx);  // (nothing of this wave's stays in flight)
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                double *out = g.Lnb[lag0 + k - 1] + (size_t)t * kPnbDoubles;
+                out[pnb_index(lane, c, 0 + q)] = fma(-al, r[k][0], h[k][0]);
+                out[pnb_index(lane, c, 3 + q)] = fma(-al, r[k][1], h[k][1]);
+                out[pnb_index(lane, c, 6 + q)] = fma(-al, r[k][2], h[k][2]);
+            }
+        };
+        static_assert(kGsMaxLag == 4, "the dispatch below lists the pass widths");
+        if (nl == 1) solve(std::integral_constant<int, 1>());
+        else if (nl == 2) solve(std::integral_constant<int, 2>());
+        else if (nl == 3) solve(std::integral_constant<int, 3>());
+        else solve(std::integral_constant<int, 4>());
         INV_STAMP(3);
         return;
     }
+    double r0 = 0.0, r1 = 0.0, r2 = 0.0;     // lane a: sum_{c <= b < a} T_ab x_b
     {
         // x_c: the unit vector; x_b = -alpha_b r_b of lane b afterwards (wave-uniform after the broadcast)
         double x0 = (q == 0) ? 1.0 : 0.0, x1 = (q == 1) ? 1.0 : 0.0, x2 = (q == 2) ? 1.0 : 0.0;
@@ -400,9 +550,17 @@ __global__ __launch_bounds__(64 * WAVES) void gs_block_inverse_kernel(const doub
             const LdsTensor tt = nx;
             lds_tensor_request(tensor_of(b + 1 < 63 ? b + 1 : 62), nx);  // step b + 1's, behind which step b computes
             __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise moves the request behind the arithmetic)
-            r0 = fma(tt.b.x, x2, fma(tt.a.y, x1, fma(tt.a.x, x0, r0)));
-            r1 = fma(tt.c.x, x2, fma(tt.b.y, x1, fma(tt.a.y, x0, r1)));
-            r2 = fma(tt.c.y, x2, fma(tt.c.x, x1, fma(tt.b.x, x0, r2)));
+            // (component by component, three independent chains interleaved: a dependent fp64 FMA issued back to back stalls a
+            //  lone wave for its pipeline latency -- same operations in the same order per component, same bits)
+            r0 = fma(tt.a.x, x0, r0);
+            r1 = fma(tt.a.y, x0, r1);
+            r2 = fma(tt.b.x, x0, r2);
+            r0 = fma(tt.a.y, x1, r0);
+            r1 = fma(tt.b.y, x1, r1);
+            r2 = fma(tt.c.x, x1, r2);
+            r0 = fma(tt.b.x, x2, r0);
+            r1 = fma(tt.c.x, x2, r1);
+            r2 = fma(tt.c.y, x2, r2);
             const double nb_al = -readlane_f64(al, b + 1 < 64 ? b + 1 : 63);
             x0 = nb_al * readlane_f64(r0, b + 1);
             x1 = nb_al * readlane_f64(r1, b + 1);
@@ -411,7 +569,7 @@ __global__ __launch_bounds__(64 * WAVES) void gs_block_inverse_kernel(const doub
         lds_tensor_wait(nx);
     }
     if (lane > c) {
-        double *out = Minv + (size_t)t * kMinvDoubles;
+        double *out = g.Minv + (size_t)t * kMinvDoubles;
         out[minv_index(lane, c, 0 + q)] = -al * r0;
         out[minv_index(lane, c, 3 + q)] = -al * r1;
         out[minv_index(lane, c, 6 + q)] = -al * r2;
@@ -438,45 +596,56 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
     int &s_ok = reinterpret_cast<int *>(spos + 3 * 64)[1];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 
+    int &s_lag = reinterpret_cast<int *>(spos + 3 * 64)[2];
     if (tid == 0) {
-        s_t = (int)__hip_atomic_fetch_add(p.flags, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // block by block: aux(t, cnt), ..., aux(t, 2), main(t), cnt = max(1, min(t, nlag)) workgroups for block t
+        const int ticket = (int)__hip_atomic_fetch_add(p.flags, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int tt = 0;
+        while (tt < p.nlag && gs_chain_ticket_base(tt + 1, p.nlag) <= ticket) ++tt;
+        if (tt == p.nlag) tt += (ticket - gs_chain_ticket_base(p.nlag, p.nlag)) / p.nlag;
+        const int cnt = tt < 1 ? 1 : (tt < p.nlag ? tt : p.nlag);
+        s_t = tt;
+        s_lag = cnt - (ticket - gs_chain_ticket_base(tt, p.nlag));  // 1 = the main workgroup
         s_ok = 1;
     }
     __syncthreads();
-    // tickets 0, 1: main(0), main(1); then aux(2), main(2), aux(3), main(3), ...
-    const int ticket = s_t;
-    const int t = (ticket < 2) ? ticket : 2 + ((ticket - 2) >> 1);
-    const bool aux = ticket >= 2 && !((ticket - 2) & 1);
+    const int t = s_t;
+    const int lag = s_lag;
+    const bool aux = lag != 1;
     if (t >= p.nb) return;
     const size_t tsz = kCoefTile * kCoefTile;
+    double2 pn[4][9];  // L(lag)_t: wave w holds the sources j = 8 w + k; pn[m][e] = {k = 2 m, k = 2 m + 1}
     if (aux) {
-        // ---- the auxiliary workgroup of block t: q_t = Q_t mu_{t-2}, nothing else
-        double2 qn[4][9];
+        // ---- an auxiliary workgroup of block t: l_t = L(lag)_t mu_{t-lag}, nothing else
         {
-            const double2 *src = reinterpret_cast<const double2 *>(p.Qnb + (size_t)t * kPnbDoubles) + (size_t)(w * 4) * 9 * 64 + lane;
+            const double2 *src = reinterpret_cast<const double2 *>((lag == 2 ? p.Lnb[1] : (lag == 3 ? p.Lnb[2] : p.Lnb[3])) + (size_t)t * kPnbDoubles) + (size_t)(w * 4) * 9 * 64 + lane;
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
-                for (int e = 0; e < 9; ++e) qn[m][e] = src[(m * 9 + e) * 64];
+                for (int e = 0; e < 9; ++e) pn[m][e] = src[(m * 9 + e) * 64];
         }
-        // far from the front: wait for an earlier block at leisure first (one lane per wave), then urgently for mu_{t-2}
-        if (t >= 7 && lane == 0) {
+        // Far from the front: wait for the block in front of the source at leisure first (one lane per wave, one load at a
+        // time), and only then urgently for mu_{t-lag}.  Urgent polls are rationed: every workgroup that spins with three
+        // loads in flight per lane adds ~70 requests to the queue of the memory channel that holds the block being
+        // published, and a dozen workgroups doing so from several block-times ahead made the publication -> consumer
+        // latency 0.96 us on the sweep's critical path where an undisturbed hand-off takes 0.47 (tools/probe).
+        if (t - lag >= 1 && lane == 0) {
             bool ok = true;
-            (void)poll_value<false>(p.mu_new + 192 * (size_t)(t - 6), p.flags, ok);
+            (void)poll_value<false>(p.mu_new + 192 * (size_t)(t - lag - 1) + 8 * w, p.flags, ok);
             if (!ok) s_ok = 0;
         }
         double *wsm = zred + 192 * w;
         if (lane < 24) {
             bool ok = true;
-            const int j = w + 8 * (lane / 3), q = lane % 3;
-            wsm[lane] = poll_value<true>(p.mu_new + 192 * (size_t)(t - 2) + 64 * q + j, p.flags, ok);
+            const int j = 8 * w + lane / 3, q = lane % 3;
+            wsm[lane] = poll_value<true>(p.mu_new + 192 * (size_t)(t - lag) + 64 * q + j, p.flags, ok);
             if (!ok) s_ok = 0;
         }
         double cx = 0.0, cy = 0.0, cz = 0.0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const double bx_ = wsm[3 * k], by_ = wsm[3 * k + 1], bz_ = wsm[3 * k + 2];  // wave-uniform: broadcast reads
-#define QNB_E(e) ((k & 1) ? qn[k >> 1][(e)].y : qn[k >> 1][(e)].x)
+#define QNB_E(e) ((k & 1) ? pn[k >> 1][(e)].y : pn[k >> 1][(e)].x)
             cx = fma(QNB_E(2), bz_, fma(QNB_E(1), by_, fma(QNB_E(0), bx_, cx)));
             cy = fma(QNB_E(5), bz_, fma(QNB_E(4), by_, fma(QNB_E(3), bx_, cy)));
             cz = fma(QNB_E(8), bz_, fma(QNB_E(7), by_, fma(QNB_E(6), bx_, cz)));
@@ -496,87 +665,97 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
                 acc.x += z.x;
                 acc.y += z.y;
             }
-            st_agent16(p.q_pub + 192 * (size_t)t + e, acc.x, acc.y);
+            st_agent16((lag == 2 ? p.pub[1] : (lag == 3 ? p.pub[2] : p.pub[3])) + 192 * (size_t)t + e, acc.x, acc.y);  // (no dynamic index into the kernel arguments: that copies them to scratch)
         }
         return;
     }
+    auto mu_of = [&](int) -> const double * { return p.mu_new; };
     GS_STAMP(0);
     if (p.stamps && tid == 0) p.stamps[(size_t)t * 16 + 12] = __builtin_amdgcn_s_memtime();  // shader clock, for the effective MHz
 
-    // ---- yU of this block = - sum_{tj >= t} Srow[tj][block t]: pair_upper_finish_kernel's sum, term for term (16 groups
-    // of terms u = g, g + 16, ...; groups added in order), through the staging area before M_t moves in
-    double f_yu_own = 0.0;
-    if (p.Srow) {
-        double *part = sM;  // [16][3][64]
-        const int nterm = p.nt_upper - t;
-        const size_t ncol = 3 * (size_t)kCoefTile * p.nt_upper;
-#pragma unroll
-        for (int gi = 0; gi < 2; ++gi) {
-            const int g = w + kChainWaves * gi;
-            double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-            for (int u0 = g; u0 < nterm; u0 += 4 * kCoefFinishGroups) {
-                double v[4][3];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int u = u0 + k * kCoefFinishGroups;
-                    const bool on = u < nterm;
-                    const double *q = p.Srow + (size_t)(t + (on ? u : 0)) * ncol + 192 * t + lane;
-                    v[k][0] = on ? q[0] : 0.0;
-                    v[k][1] = on ? q[64] : 0.0;
-                    v[k][2] = on ? q[128] : 0.0;
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    s0 += v[k][0];
-                    s1 += v[k][1];
-                    s2 += v[k][2];
-                }
-            }
-            part[(g * 3 + 0) * 64 + lane] = s0;
-            part[(g * 3 + 1) * 64 + lane] = s1;
-            part[(g * 3 + 2) * 64 + lane] = s2;
-        }
-        __syncthreads();
-        if (tid < 192) {
-            double acc = 0.0;
-#pragma unroll
-            for (int k = 0; k < kCoefFinishGroups; ++k) acc += part[(k * 3 + w) * 64 + lane];
-            f_yu_own = -acc;
-        }
-        __syncthreads();  // (M_t is staged over these words next)
-    }
-    // ---- the target block's coordinates and per-atom operands (small, requested first), then M_t (folded layout, 16-B
-    // loads) into LDS.  The operands of the final steps (component q = tid / 64 of atom i = tid % 64) are PARKED in the rows
-    // of zred the source loop does not use, so that neither their registers burden that loop nor their load latency
-    // (~0.6 us) sits between the last source and w_t.
-    if (tid < 192) {
-        const double *src = (tid < 64) ? p.px : (tid < 128 ? p.py : p.pz);
-        const int k = 64 * t + lane;
-        const double v_pos = src[k], v_al = p.alpha[k], v_es = p.es[3 * k + w];
-        const double v_yu = p.Srow ? f_yu_own : p.y[3 * k + w];
-        spos[tid] = v_pos;
-        zred[192 + tid] = v_al;
-        zred[384 + tid] = v_es;
-        zred[576 + tid] = v_yu;
-    }
+    // Everything the prologue reads from memory is requested up front -- M_t (folded layout, 16-byte loads, 288 B per
+    // lane), the block's per-atom operands, the upper-triangle row sums -- so that the round trips (cold at the start of
+    // a launch: ~1.5 us each, and the first blocks' prologue is on the sweep's critical path) overlap; round 3's first
+    // version fetched them one after the other (stamps: 3.9 us from start to "staged").
     {
         const double2 *src = reinterpret_cast<const double2 *>(p.Minv + (size_t)t * kMinvDoubles);
         double2 *dst = reinterpret_cast<double2 *>(sM);
         double2 r[kMinvDoubles / 2 / kChainThreads];
 #pragma unroll
         for (int k = 0; k < kMinvDoubles / 2 / kChainThreads; ++k) r[k] = src[k * kChainThreads + tid];
+        double v_pos = 0.0, v_al = 0.0, v_es = 0.0, v_y = 0.0;
+        if (tid < 192) {
+            const int k = 64 * t + lane;
+            v_pos = ((tid < 64) ? p.px : (tid < 128 ? p.py : p.pz))[k];
+            v_al = p.alpha[k];
+            v_es = p.es[3 * k + w];
+            if (!p.Srow) v_y = p.y[3 * k + w];
+        }
+        // ---- yU of this block = - sum_{tj >= t} Srow[tj][block t]: pair_upper_finish_kernel's sum, term for term (16 groups
+        // of terms u = g, g + 16, ...; groups added in order)
+        double sg[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+        if (p.Srow) {
+            const int nterm = p.nt_upper - t;
+            const size_t ncol = 3 * (size_t)kCoefTile * p.nt_upper;
+#pragma unroll
+            for (int gi = 0; gi < 2; ++gi) {
+                const int g = w + kChainWaves * gi;
+                for (int u0 = g; u0 < nterm; u0 += 4 * kCoefFinishGroups) {
+                    double v[4][3];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int u = u0 + k * kCoefFinishGroups;
+                        const bool on = u < nterm;
+                        const double *q = p.Srow + (size_t)(t + (on ? u : 0)) * ncol + 192 * t + lane;
+                        v[k][0] = on ? q[0] : 0.0;
+                        v[k][1] = on ? q[64] : 0.0;
+                        v[k][2] = on ? q[128] : 0.0;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        sg[gi][0] += v[k][0];
+                        sg[gi][1] += v[k][1];
+                        sg[gi][2] += v[k][2];
+                    }
+                }
+            }
+        }
 #pragma unroll
         for (int k = 0; k < kMinvDoubles / 2 / kChainThreads; ++k) dst[k * kChainThreads + tid] = r[k];
+        double acc = 0.0;
+        if (p.Srow) {
+            // the 16 group sums pass through zred eight at a time (groups 0..7, then 8..15: the order of the finish kernel)
+#pragma unroll
+            for (int gi = 0; gi < 2; ++gi) {
+                zred[(w * 3 + 0) * 64 + lane] = sg[gi][0];
+                zred[(w * 3 + 1) * 64 + lane] = sg[gi][1];
+                zred[(w * 3 + 2) * 64 + lane] = sg[gi][2];
+                __syncthreads();
+                if (tid < 192) {
+#pragma unroll
+                    for (int k = 0; k < kChainWaves; ++k) acc += zred[(k * 3 + w) * 64 + lane];
+                }
+                __syncthreads();
+            }
+        }
+        // The operands of the final steps (component q = tid / 64 of atom i = tid % 64) are PARKED in the rows of zred the
+        // source loop does not use, so that neither their registers burden that loop nor their load latency (~0.6 us) sits
+        // between the last source and w_t.
+        if (tid < 192) {
+            spos[tid] = v_pos;
+            zred[192 + tid] = v_al;
+            zred[384 + tid] = v_es;
+            zred[576 + tid] = p.Srow ? -acc : v_y;
+        }
     }
     __syncthreads();
     GS_STAMP(1);
-    // ---- P_t = M_t D T(t,t-1) into registers: wave w takes the sources j = w + 8 k; pn[m][e] = {k = 2 m, k = 2 m + 1}.
+    // ---- P_t = M_t D T(t,t-1) into registers: wave w takes the sources j = 8 w + k; pn[m][e] = {k = 2 m, k = 2 m + 1}.
     // Requested BEHIND the barrier that ends the staging of M_t: nothing waits for these 288 KB until the product with
     // mu_{t-1}, so the first blocks of a sweep (whose turn comes before the loads have landed) can form w_t meanwhile --
     // in front of the barrier they delayed every block's staging by 2.2 us (stamps), i.e. the start of every sweep.
-    double2 pn[4][9];
     if (t >= 1) {
-        const double2 *src = reinterpret_cast<const double2 *>(p.Pnb + (size_t)t * kPnbDoubles) + (size_t)(w * 4) * 9 * 64 + lane;
+        const double2 *src = reinterpret_cast<const double2 *>(p.Lnb[0] + (size_t)t * kPnbDoubles) + (size_t)(w * 4) * 9 * 64 + lane;
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -592,7 +771,7 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
     // rotation) is the one its next step needs, across tile boundaries too (round 2 alternated forward and backward
     // passes, which needs each tile whole).
     double ax = 0.0, ay = 0.0, az = 0.0;  // lane l: this wave's share of sum_s T(t,s) mu_s for target atom (l + 8 (w + n)) & 63
-    const int ns = (p.ablate & 1) ? 0 : (t >= 2 ? t - 2 : 0);
+    const int ns = (p.ablate & 1) ? 0 : (t > p.nlag ? t - p.nlag : 0);
     {
         double2 c[4][2];
         double *sps = zred;  // [3][64] coordinates of the source block being multiplied
@@ -616,30 +795,32 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
         double spec_pos = 0.0;
         auto spec_issue = [&](int s) {
             if (tid < 192) {
-                if (!(p.ablate & 4)) spec = ld_agent_u64(reinterpret_cast<const unsigned long long *>(p.mu_new) + 192 * (size_t)s + tid);
+                if (!(p.ablate & 4)) spec = ld_agent_u64(reinterpret_cast<const unsigned long long *>(mu_of(s)) + 192 * (size_t)s + tid);
                 spec_pos = ((tid < 64) ? p.px : (tid < 128 ? p.py : p.pz))[64 * s + lane];
             }
             spec2 = kGsSentinel;
         };
         auto spec_again = [&](int s) {
-            if (tid < 192 && !(p.ablate & 4)) spec2 = ld_agent_u64(reinterpret_cast<const unsigned long long *>(p.mu_new) + 192 * (size_t)s + tid);
+            if (tid < 192 && !(p.ablate & 4)) spec2 = ld_agent_u64(reinterpret_cast<const unsigned long long *>(mu_of(s)) + 192 * (size_t)s + tid);
         };
+        // (LDS-only barriers: __syncthreads() would also wait for every global load of the wave -- the quarters of the next
+        //  tile requested a moment ago -- i.e. put a memory round trip, ~0.45 us by the stamps, between two tiles)
         auto fetch_mu = [&](int s) {  // mu_s -> smu[q][atom] (the published layout), its coordinates -> sps; false on a give-up
-            __syncthreads();          // the previous tile's readers are done with smu / sps
+            lds_barrier();            // the previous tile's readers are done with smu / sps
             if (tid < 192) {
                 bool ok = true;
                 if (spec == kGsSentinel) spec = spec2;
                 double v = __longlong_as_double((long long)spec);
                 if (p.ablate & 4)
                     v = 1e-3;
-                else if (spec == kGsSentinel)  // not there yet: poll (urgently when close to the neighbour)
-                    v = (t - s <= 4) ? poll_value<true>(p.mu_new + 192 * (size_t)s + tid, p.flags, ok)
-                                     : poll_value<false>(p.mu_new + 192 * (size_t)s + tid, p.flags, ok);
+                else if (spec == kGsSentinel)  // not there yet: poll, one load at a time (the tail has block-times of slack;
+                                               // urgent polls are kept for the critical section, see the rationing note)
+                    v = poll_value<false>(mu_of(s) + 192 * (size_t)s + tid, p.flags, ok);
                 smu[tid] = v;
                 sps[tid] = spec_pos;
                 if (!ok) s_ok = 0;
             }
-            __syncthreads();
+            lds_barrier();
             return s_ok != 0;
         };
         if (ns > 0) {
@@ -697,9 +878,16 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
     if (!s_ok) return;
     GS_STAMP(6);
 
-    // ---- w_t = M_t D (e + yU - sum_{s <= t-2} T(t,s) mu_s): everything that does not need mu_{t-1}.  It hangs on
-    // mu_{t-2}, which is published one block-time before mu_{t-1}, so these three barrier-separated stages (the v_t and
-    // M_t v_t stages of round 2's critical section: 0.16 + 0.6 us by its stamps) run while block t-1 is in ITS last stage.
+    // ---- w_t = M_t D (e + yU - sum_{s <= t-nlag-1} T(t,s) mu_s) - sum_{k >= 3} l(k)_t: everything that needs neither
+    // mu_{t-1} nor q_t.  It hangs on mu_{t-nlag-1}, nlag block-times before mu_{t-1}, so these barrier-separated stages
+    // (the v_t and M_t v_t stages of round 2's critical section) run while the blocks in front are in THEIR last stages.
+    // (The l(k)_t of the auxiliary workgroups are fetched in the critical section, by waves that would otherwise idle at
+    // its first barrier: fetched here -- requested before the M_t product, looked at behind it -- the lag-3 vector was
+    // usually a fraction of a microsecond too late and cost this stage a dependent round trip, stamps 1.9 vs 1.3 us.)
+    // (and one word of mu_{t-2}: is this workgroup EARLY?  Then it waits for that block at leisure before it
+    //  starts to poll mu_{t-1} urgently -- see the auxiliary workgroups' rationing above)
+    unsigned long long early = 0ull;
+    if (t >= 2 && tid == 0) early = ld_agent_u64(reinterpret_cast<const unsigned long long *>(p.mu_new + 192 * (size_t)(t - 2)));
     if (tid < 192) {
         double sum = 0.0;
 #pragma unroll
@@ -766,56 +954,78 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
     lds_barrier();  // zred is free again: every wave stages its share of the hand-off in its own rows below
     GS_STAMP(7);
 
-    // ---- the critical path: mu_{t-1} -> P_t mu_{t-1} -> cross-wave sum -> publish.  One barrier.
+    // ---- the critical path: mu_{t-1} -> LDS -> P_t mu_{t-1} -> cross-wave sum -> publish.  Two LDS-only barriers.
     if (t >= 1) {
-        // Every wave fetches the 24 doubles IT needs (its 8 source atoms x 3 components) with its first 24 lanes and
-        // spreads them through 24 words of LDS that only this wave touches (the head of its own zred rows): no workgroup
-        // barrier between the hand-off and the product (a wave's LDS operations execute in order).
-        double *wsm = zred + 192 * w;
-        // ... and, with lanes 32..55, 24 of the 192 doubles of q_t (published about one hand-off EARLIER by the block's
-        // auxiliary workgroup, so they do not hold the wave up), which go to smu for the lanes that publish: no dependent
-        // load of q_t behind the product (that cost 0.2 us per block when the publishing lanes fetched it themselves).
-        const bool qlane = t >= 2 && lane >= 32 && lane < 56;
-        if (lane < 24 || qlane) {
-            bool ok = true;
-            const int j = w + 8 * (lane / 3), q = lane % 3;
-            const double *src = qlane ? p.q_pub + 192 * (size_t)t + 24 * w + (lane - 32)
-                                      : p.mu_new + 192 * (size_t)(t - 1) + 64 * q + j;
-            const double v = poll_value<true>(src, p.flags, ok);
-            if (qlane)
-                smu[24 * w + (lane - 32)] = v;
-            else
-                wsm[lane] = v;
-            if (!ok) s_ok = 0;
+        // ONE wave fetches mu_{t-1} -- all 192 doubles, three per lane, requested together -- and spreads it through LDS
+        // (spos: the target coordinates are no longer needed); wave 1 does the same for q_t (published about a hand-off
+        // EARLIER by the block's auxiliary workgroup, so it is there at the first look); the others wait at the barrier.
+        // Round 3 first let every wave poll the 24 doubles it multiplies (no barrier here): the product then starts when
+        // the LAST of eight independent pollers has seen its share -- each is up to a round trip out of phase with the
+        // publication -- and tools/probe/handoff_probe measures that shape at 0.73-0.77 us per hop against 0.58-0.63 for
+        // this one (and 0.47 for a bare one-word hop).
+        if (w == 0) {
+            if (early == kGsSentinel) {  // (lane 0: this workgroup was early -- mu_{t-2} had not been published a product ago)
+                bool ok = true;
+                (void)poll_value<false>(p.mu_new + 192 * (size_t)(t - 2), p.flags, ok);
+                if (!ok) s_ok = 0;
+            }
+            double a, b, c;
+            if (!poll_three(mu_of(t - 1) + 192 * (size_t)(t - 1) + lane, p.flags, a, b, c)) s_ok = 0;
+            spos[lane] = a;
+            spos[64 + lane] = b;
+            spos[128 + lane] = c;
+        } else if (w < p.nlag && t > w) {  // waves 1 .. nlag-1: the vector of lag w + 1 (q_t -> smu, the others -> the head of
+                                           // sM: the inverse is no longer needed)
+            double a, b, c;
+            if (!poll_three((w == 1 ? p.pub[1] : (w == 2 ? p.pub[2] : p.pub[3])) + 192 * (size_t)t + lane, p.flags, a, b, c)) s_ok = 0;
+            double *dst = (w == 1) ? smu : sM + 192 * (w - 2);
+            dst[lane] = a;
+            dst[64 + lane] = b;
+            dst[128 + lane] = c;
         }
+        lds_barrier();
         GS_STAMP(8);
         if (p.ablate & 8) {  // republish what was polled (+1), nothing else
-            if (lane < 24) {
-                const int j = w + 8 * (lane / 3), q = lane % 3;
-                st_agent(p.mu_new + 192 * (size_t)t + 64 * q + j, wsm[lane] + 1.0);
-            }
+            if (tid < 192) st_agent(p.mu_new + 192 * (size_t)t + tid, spos[tid] + 1.0);
             return;
         }
         double bx_[8], by_[8], bz_[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {  // wave-uniform: broadcast reads
-            bx_[k] = wsm[3 * k];
-            by_[k] = wsm[3 * k + 1];
-            bz_[k] = wsm[3 * k + 2];
+        for (int k = 0; k < 8; ++k) {  // wave-uniform: broadcast reads (this wave's sources j = 8 w + k)
+            bx_[k] = spos[8 * w + k];
+            by_[k] = spos[64 + 8 * w + k];
+            bz_[k] = spos[128 + 8 * w + k];
         }
-        double cx = 0.0, cy = 0.0, cz = 0.0;
+        // six independent accumulation chains (even and odd sources apart, added at the end): the 72 FMAs of this product
+        // are the arithmetic on the sweep's critical path, and a chain of dependent fp64 FMAs issues at its latency
+        double cxa = 0.0, cya = 0.0, cza = 0.0, cxb = 0.0, cyb = 0.0, czb = 0.0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-#define PNB_E(e) ((k & 1) ? pn[k >> 1][(e)].y : pn[k >> 1][(e)].x)
-            cx = fma(PNB_E(2), bz_[k], fma(PNB_E(1), by_[k], fma(PNB_E(0), bx_[k], cx)));
-            cy = fma(PNB_E(5), bz_[k], fma(PNB_E(4), by_[k], fma(PNB_E(3), bx_[k], cy)));
-            cz = fma(PNB_E(8), bz_[k], fma(PNB_E(7), by_[k], fma(PNB_E(6), bx_[k], cz)));
-#undef PNB_E
+        for (int m = 0; m < 4; ++m) {
+            const int ka = 2 * m, kb = 2 * m + 1;
+            cxa = fma(pn[m][0].x, bx_[ka], cxa);
+            cya = fma(pn[m][3].x, bx_[ka], cya);
+            cza = fma(pn[m][6].x, bx_[ka], cza);
+            cxb = fma(pn[m][0].y, bx_[kb], cxb);
+            cyb = fma(pn[m][3].y, bx_[kb], cyb);
+            czb = fma(pn[m][6].y, bx_[kb], czb);
+            cxa = fma(pn[m][1].x, by_[ka], cxa);
+            cya = fma(pn[m][4].x, by_[ka], cya);
+            cza = fma(pn[m][7].x, by_[ka], cza);
+            cxb = fma(pn[m][1].y, by_[kb], cxb);
+            cyb = fma(pn[m][4].y, by_[kb], cyb);
+            czb = fma(pn[m][7].y, by_[kb], czb);
+            cxa = fma(pn[m][2].x, bz_[ka], cxa);
+            cya = fma(pn[m][5].x, bz_[ka], cya);
+            cza = fma(pn[m][8].x, bz_[ka], cza);
+            cxb = fma(pn[m][2].y, bz_[kb], cxb);
+            cyb = fma(pn[m][5].y, bz_[kb], cyb);
+            czb = fma(pn[m][8].y, bz_[kb], czb);
         }
-        zred[(w * 3 + 0) * 64 + lane] = cx;  // (over the staged hand-off, which this wave has read)
+        const double cx = cxa + cxb, cy = cya + cyb, cz = cza + czb;
+        zred[(w * 3 + 0) * 64 + lane] = cx;
         zred[(w * 3 + 1) * 64 + lane] = cy;
         zred[(w * 3 + 2) * 64 + lane] = cz;
-        __syncthreads();
+        lds_barrier();
         if (!s_ok) return;
         GS_STAMP(9);
     }
@@ -823,6 +1033,14 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
     if (tid < 96) {
         const int e = 2 * tid;
         double2 mu = wt;
+#pragma unroll
+        for (int k = 3; k <= kGsMaxLag; ++k) {  // - l(k)_t, in the order of the lags
+            if (k <= p.nlag && t >= k) {
+                const double2 lt = *reinterpret_cast<const double2 *>(sM + 192 * (k - 3) + e);
+                mu.x -= lt.x;
+                mu.y -= lt.y;
+            }
+        }
         if (t >= 2) {  // q_t = Q_t mu_{t-2}, staged in smu by the polling lanes
             const double2 qt = *reinterpret_cast<const double2 *>(smu + e);
             mu.x -= qt.x;
@@ -840,10 +1058,16 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
             mu.x -= acc.x;
             mu.y -= acc.y;
         }
-        if (t != p.fault_block) st_agent16(p.mu_new + 192 * (size_t)t + e, mu.x, mu.y);
+        if (t != p.fault_block) {
+            st_agent16(p.mu_new + 192 * (size_t)t + e, mu.x, mu.y);
+        }
         *reinterpret_cast<double2 *>(smu + e) = mu;
     }
     GS_STAMP(10);
+    if (p.stamps && tid == 0) {  // (diagnostic: when this wave's write-through stores had been acknowledged)
+        __builtin_amdgcn_s_waitcnt(0);
+        p.stamps[(size_t)t * 16 + 14] = __builtin_amdgcn_s_memrealtime();
+    }
     __syncthreads();
     GS_STAMP(11);
     if (p.stamps && tid == 0) p.stamps[(size_t)t * 16 + 13] = __builtin_amdgcn_s_memtime();

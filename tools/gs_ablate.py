@@ -11,6 +11,8 @@ masks = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 1
 s = synth.s_pol(n)
 p = dict(temperature=77.0, polarization=1, polar_damp=2.1304, polar_gs=1, polar_max_iter=4)
 e = engine.Engine(n)
+if os.environ.get("MPMC_GS_LAGS"):
+    e.set_option("gs_lags", int(os.environ["MPMC_GS_LAGS"]))
 e.load_system(s, p)
 e.energy()
 pos = s["pos"].copy()

@@ -1,3 +1,4 @@
+import os
 import sys
 sys.path.insert(0,'/root/repo')
 import numpy as np
@@ -5,6 +6,8 @@ from mpmc_amd import engine, synth
 s = synth.s_pol(4096)
 p = dict(synth.FLAGS_POL_PRODUCTION)
 e = engine.Engine(4096)
+if os.environ.get("MPMC_GS_LAGS"):
+    e.set_option("gs_lags", int(os.environ["MPMC_GS_LAGS"]))
 e.load_system(s, p)
 e.energy()
 pos = s["pos"].copy()
