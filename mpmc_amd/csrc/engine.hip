@@ -338,6 +338,10 @@ struct mpmc_hip_ctx {
     int opt_spec_rank = 1;
     unsigned long long spec_redos = 0;
     hipEvent_t ev_rank = nullptr;
+    hipStream_t stream3 = nullptr;         // the chain-data builder of the main stream's view runs here, beside that stream's next kernels
+    hipEvent_t ev_bfork = nullptr, ev_bjoin = nullptr;
+    bool build_join_pending = false;       // the main stream has not yet waited for the builder launch of this call
+    int opt_gs_build_fork = 1;             // "gs_build_fork": 0 = the builder in the main stream (A/B)
     int *h_order = nullptr;               // pinned staging of set_sweep_order (2 x max_npad ints)
     hipEvent_t ev_order = nullptr;
     double *h_rank = nullptr;             // pinned, max_npad
@@ -551,6 +555,8 @@ extern "C" int mpmc_hip_set_option(mpmc_hip_ctx *c, const char *name, int value)
         c->opt_fuse_moves = value;  // 0: apply_moves_kernel + update_coef_kernel as two launches (A/B; bit-identical)
     else if (!strcmp(name, "resident_fault"))
         c->opt_res_fault = value;  // test hook: the next resident launch loses a hand-off (-> fallback)
+    else if (!strcmp(name, "gs_build_fork"))
+        c->opt_gs_build_fork = value;
     else if (!strcmp(name, "gs_lags")) {
         if (value < 2 || value > kGsMaxLag) return fail("mpmc_hip_set_option: gs_lags must be 2 .. %d", kGsMaxLag);
         if (value != c->opt_gs_lags) c->view[0].M_epoch = c->view[1].M_epoch = 0;  // (the matrices of the new lags are not there)
@@ -648,6 +654,9 @@ extern "C" int mpmc_hip_create(mpmc_hip_ctx **out, int device, int max_atoms) {
     HIPCHK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
     HIPCHK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest));
     HIPCHK(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_least));
+    HIPCHK(hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_greatest));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_bfork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_bjoin, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_rank, hipEventDisableTiming));
@@ -761,6 +770,9 @@ extern "C" void mpmc_hip_destroy(mpmc_hip_ctx *c) {
     }
     graph_destroy(c);
     if (c->stream2) hipStreamDestroy(c->stream2);
+    if (c->stream3) hipStreamDestroy(c->stream3);
+    if (c->ev_bfork) hipEventDestroy(c->ev_bfork);
+    if (c->ev_bjoin) hipEventDestroy(c->ev_bjoin);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
     if (c->ev_rank) hipEventDestroy(c->ev_rank);
@@ -1980,6 +1992,10 @@ static int enqueue_direct(mpmc_hip_ctx *c) {
     if (side_rc) return -1;
     if (c->pending.n > 0 && flush_moves(c)) return -1;  // (a move no launch of this call carried: cannot happen, but cheap)
     c->moves_in_pair = false;
+    if (c->build_join_pending) {  // (a builder launch no chain launch of this call waited for)
+        hipStreamWaitEvent(c->stream, c->ev_bjoin, 0);
+        c->build_join_pending = false;
+    }
     if (two_streams && !c->call_split) hipStreamWaitEvent(c->stream, c->ev_join, 0);
     const bool timed_call = is_timed_call(c);
     if (timed_call) hipEventRecord(c->ev_last, c->stream);
