@@ -454,7 +454,7 @@ def main():
     for var, opt in (("MPMC_OVERLAP", "overlap_streams"), ("MPMC_SIDE_AFTER", "side_after"),
                      ("MPMC_STEP_GRAPH", "step_graph"), ("MPMC_SYM_MODE", "sym_mode"), ("MPMC_GS_DEBUG", "persistent_gs"),
                      ("MPMC_RESIDENT", "resident_jacobi"), ("MPMC_RESIDENT_FOLD", "resident_fold"), ("MPMC_SIDE_MOVES", "side_moves"), ("MPMC_SPLIT_RECORD", "split_record"), ("MPMC_FUSE_FIELD", "fuse_field"), ("MPMC_RANK_LATE", "rank_late"), ("MPMC_FUSE_RECIP", "fuse_recip"), ("MPMC_FUSE_TENSOR", "fuse_tensor"), ("MPMC_GS_FOLD_UPPER", "gs_fold_upper"), ("MPMC_RANK_VIEW_SIDE", "rank_view_side"), ("MPMC_SWEEP_ALTERNATE", "sweep_alternate"),
-                     ("MPMC_SWEEP_NT", "sweep_nt"), ("MPMC_SWEEP_SPLIT", "sweep_split"), ("MPMC_GS_FUSE_MOVES", "gs_fuse_moves"), ("MPMC_GS_LAGS", "gs_lags"), ("MPMC_GS_BUILD_FORK", "gs_build_fork"), ("MPMC_FUSE_MOVES", "fuse_moves"), ("MPMC_GS_FOLD_FINISH", "gs_fold_finish")):
+                     ("MPMC_SWEEP_NT", "sweep_nt"), ("MPMC_SWEEP_SPLIT", "sweep_split"), ("MPMC_GS_FUSE_MOVES", "gs_fuse_moves"), ("MPMC_GS_LAGS", "gs_lags"), ("MPMC_GS_BUILD_FORK", "gs_build_fork"), ("MPMC_GS_SIDE_WAVES", "gs_side_waves"), ("MPMC_FUSE_MOVES", "fuse_moves"), ("MPMC_GS_FOLD_FINISH", "gs_fold_finish")):
         if os.environ.get(var):
             chain.set_option(opt, int(os.environ[var]))
     if args.full_sweep or args.full_rebuild or args.expanded_matrix:

@@ -624,34 +624,35 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
 #pragma unroll
                 for (int e = 0; e < 9; ++e) pn[m][e] = src[(m * 9 + e) * 64];
         }
-        // Far from the front: wait for the block in front of the source at leisure first (one lane per wave, one load at a
-        // time), and only then urgently for mu_{t-lag}.  Urgent polls are rationed: every workgroup that spins with three
-        // loads in flight per lane adds ~70 requests to the queue of the memory channel that holds the block being
-        // published, and a dozen workgroups doing so from several block-times ahead made the publication -> consumer
-        // latency 0.96 us on the sweep's critical path where an undisturbed hand-off takes 0.47 (tools/probe).
-        if (t - lag >= 1 && lane == 0) {
-            bool ok = true;
-            (void)poll_value<false>(p.mu_new + 192 * (size_t)(t - lag - 1) + 8 * w, p.flags, ok);
-            if (!ok) s_ok = 0;
+        // Far from the front: wait for the block in front of the source at leisure first (one lane, one load at a time), and
+        // only then for mu_{t-lag} -- with ONE wave, like the main workgroup's critical section (the shape with the shortest
+        // hop, and every additional poller of a block being published lengthens everybody's: with each wave of every
+        // auxiliary workgroup polling its own 24 doubles, three loads in flight per lane, the publication -> consumer latency
+        // on the sweep's critical path was 0.96 us where an undisturbed hand-off takes 0.47, tools/probe).
+        if (w == 0) {
+            if (t - lag >= 1 && lane == 0) {
+                bool ok = true;
+                (void)poll_value<false>(p.mu_new + 192 * (size_t)(t - lag - 1), p.flags, ok);
+                if (!ok) s_ok = 0;
+            }
+            double a, b, c;
+            if (!poll_three(p.mu_new + 192 * (size_t)(t - lag) + lane, p.flags, a, b, c)) s_ok = 0;
+            spos[lane] = a;
+            spos[64 + lane] = b;
+            spos[128 + lane] = c;
         }
-        double *wsm = zred + 192 * w;
-        if (lane < 24) {
-            bool ok = true;
-            const int j = 8 * w + lane / 3, q = lane % 3;
-            wsm[lane] = poll_value<true>(p.mu_new + 192 * (size_t)(t - lag) + 64 * q + j, p.flags, ok);
-            if (!ok) s_ok = 0;
-        }
+        lds_barrier();
         double cx = 0.0, cy = 0.0, cz = 0.0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const double bx_ = wsm[3 * k], by_ = wsm[3 * k + 1], bz_ = wsm[3 * k + 2];  // wave-uniform: broadcast reads
+            const double bx_ = spos[8 * w + k], by_ = spos[64 + 8 * w + k], bz_ = spos[128 + 8 * w + k];  // wave-uniform: broadcast reads
 #define QNB_E(e) ((k & 1) ? pn[k >> 1][(e)].y : pn[k >> 1][(e)].x)
             cx = fma(QNB_E(2), bz_, fma(QNB_E(1), by_, fma(QNB_E(0), bx_, cx)));
             cy = fma(QNB_E(5), bz_, fma(QNB_E(4), by_, fma(QNB_E(3), bx_, cy)));
             cz = fma(QNB_E(8), bz_, fma(QNB_E(7), by_, fma(QNB_E(6), bx_, cz)));
 #undef QNB_E
         }
-        zred[(w * 3 + 0) * 64 + lane] = cx;  // (over the staged hand-off, which this wave has read)
+        zred[(w * 3 + 0) * 64 + lane] = cx;
         zred[(w * 3 + 1) * 64 + lane] = cy;
         zred[(w * 3 + 2) * 64 + lane] = cz;
         __syncthreads();
