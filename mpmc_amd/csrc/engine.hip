@@ -133,6 +133,9 @@ struct SweepView {
     double *Minv = nullptr;      // [cap/64][kMinvDoubles]
     double *Lnb[kGsMaxLag] = {nullptr, nullptr, nullptr, nullptr};  // [k-1]: [cap/64][kPnbDoubles], L(k)_t = M_t D T(t,t-k)
     int Lnb_lags = 0;            // how many of them are allocated
+    int nlag = 0, nlag_built = 0;   // lags this view's chain uses / has matrices for (decided at a whole-view rebuild)
+    long long last_full_call = -1;  // energy_calls of the view's last whole rebuild
+    int full_streak = 0;            // consecutive calls that rebuilt it as a whole
     unsigned long long C_epoch = 0;   // bumped by every full build of C
     unsigned long long M_epoch = 0;   // C_epoch the chain data were last fully built under (0: never)
     unsigned long long M_call = 0;    // energy() call that last maintained them

@@ -27,6 +27,8 @@ python tools/inv_stamps.py 4096 2>&1 | grep INV_STAMPS > gpurun_out/r03_inverse_
 python tools/gs_ablate.py 4096 0,1,2,4 > gpurun_out/r03_chain_ablations.txt 2>&1
 bash tools/ab_lib.sh tools/ab/libmpmc_hip_tnb.so r02chain -- --workload spolprod_4096 --steps 1500 --warmup 150 > gpurun_out/r03_ab_chain_4096.txt 2>&1
 bash tools/ab_lib.sh tools/ab/libmpmc_hip_tnb.so r02chain -- --workload spolprod_1024 --steps 1500 --warmup 150 > gpurun_out/r03_ab_chain_1024.txt 2>&1
+echo "== time line of a production step (kernel trace; host API trace separately)"
+rm -rf gpurun_out/tl; rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl -- python3 bench.py --workload spolprod_4096 --steps 300 --warmup 50 --no-cpu-baseline > /dev/null 2>&1 && python tools/step_timeline.py gpurun_out/tl 200 > gpurun_out/r03_step_timeline.txt; rm -rf gpurun_out/tl
 echo "== counters under the VALU kernels"
 bash profiles/valu_counters.sh r03_jacobi > gpurun_out/prof_r03_valu.log 2>&1 || echo "valu counters failed"
 echo ALL DONE
