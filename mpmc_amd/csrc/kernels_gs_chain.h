@@ -70,10 +70,6 @@ constexpr int kChainWaves = 8;
 constexpr int kChainThreads = 64 * kChainWaves;
 constexpr unsigned kGsSpinLimit = 1u << 22;  // ~3 s of polling; a legitimate wait is at most one sweep (< 1 ms)
 constexpr unsigned long long kGsSentinel = 0x7ff8dead7ff8deadull;  // a NaN no arithmetic produces
-#ifndef GS_POLL_VARIANT
-#define GS_POLL_VARIANT 0  // timing experiments (tools/ab builds): urgent polls 1 = one load at a time, no sleep; 2 = two in flight;
-                           // 3 = the critical section's block poll with two attempts in flight
-#endif
 
 // ---- cached block inverse M_t, "folded" so that one wave instruction is always fully used:
 //   group g (0..31), element e = 3 p + q (row component p, column component q), lane l:
@@ -182,52 +178,19 @@ __device__ __forceinline__ unsigned long long ld_agent_u64(const unsigned long l
     return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Poll one double until it differs from the sentinel (agent-scope loads bypass the never-refreshed L1).
-// URGENT: three loads are kept in flight, so the value is seen within one issue interval (~0.1 us) of its arrival
-// instead of one load round trip (~0.7 us): for the hand-offs on the sweep's critical path.  Otherwise one load at a
-// time with a longer sleep (a workgroup far behind the front only has to notice within several block times).
+// Poll one double until it differs from the sentinel (agent-scope loads bypass the never-refreshed L1): one load at a time
+// with a short sleep -- for the waits that have block-times of slack (far sources, the "is the front near?" looks).  The
+// hand-offs on the sweep's critical path use poll_three() below.  (Rounds 2-3 also had an urgent form with two or three
+// loads in flight per lane; every such variant measured slower once more than one workgroup polls a block -- DESIGN.md 3.)
 template <bool URGENT>
 __device__ __forceinline__ double poll_value(const double *p, unsigned *flags, bool &ok) {
+    static_assert(!URGENT, "the urgent form is gone: poll_three()");
     const unsigned long long *q = reinterpret_cast<const unsigned long long *>(p);
-    const unsigned limit = kGsSpinLimit;
-    if (URGENT && GS_POLL_VARIANT == 1) {
-        for (unsigned it = 0; it < 16 * limit; ++it) {
-            const unsigned long long v = ld_agent_u64(q);
-            if (v != kGsSentinel) return __longlong_as_double((long long)v);
-            if ((it & 1023u) == 1023u && __hip_atomic_load(flags + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-        }
-    } else if (URGENT && GS_POLL_VARIANT == 2) {
-        unsigned long long v0 = ld_agent_u64(q);
-        __builtin_amdgcn_s_sleep(2);
-        unsigned long long v1 = ld_agent_u64(q);
-        for (unsigned it = 0; it < 4 * limit; ++it) {
-            if (v0 != kGsSentinel) return __longlong_as_double((long long)v0);
-            v0 = v1;
-            if ((it & 1023u) == 1023u && __hip_atomic_load(flags + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-            v1 = ld_agent_u64(q);
-            __builtin_amdgcn_s_sleep(2);
-        }
-    } else if (URGENT) {
-        unsigned long long v0 = ld_agent_u64(q);
-        __builtin_amdgcn_s_sleep(1);
-        unsigned long long v1 = ld_agent_u64(q);
-        __builtin_amdgcn_s_sleep(1);
-        unsigned long long v2 = ld_agent_u64(q);
-        for (unsigned it = 0; it < 4 * limit; ++it) {
-            if (v0 != kGsSentinel) return __longlong_as_double((long long)v0);
-            v0 = v1;
-            v1 = v2;
-            if ((it & 1023u) == 1023u && __hip_atomic_load(flags + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-            v2 = ld_agent_u64(q);
-            __builtin_amdgcn_s_sleep(1);
-        }
-    } else {
-        for (unsigned it = 0; it < limit; ++it) {
-            const unsigned long long v = ld_agent_u64(q);
-            if (v != kGsSentinel) return __longlong_as_double((long long)v);
-            if ((it & 255u) == 255u && __hip_atomic_load(flags + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-            __builtin_amdgcn_s_sleep(4);
-        }
+    for (unsigned it = 0; it < kGsSpinLimit; ++it) {
+        const unsigned long long v = ld_agent_u64(q);
+        if (v != kGsSentinel) return __longlong_as_double((long long)v);
+        if ((it & 255u) == 255u && __hip_atomic_load(flags + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        __builtin_amdgcn_s_sleep(4);
     }
     if (__hip_atomic_exchange(flags + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
         // first to give up: leave a breadcrumb (which workgroup, which thread, low address bits)
@@ -243,25 +206,6 @@ __device__ __forceinline__ double poll_value(const double *p, unsigned *flags, b
 // attempt in flight TOGETHER: one round trip per attempt for the whole block when a full wave calls this.
 __device__ __forceinline__ bool poll_three(const double *p, unsigned *flags, double &a, double &b, double &c) {
     const unsigned long long *q = reinterpret_cast<const unsigned long long *>(p);
-#if GS_POLL_VARIANT == 3  // (timing experiment: two attempts in flight, half a round trip apart)
-    {
-        unsigned long long ua = ld_agent_u64(q), ub = ld_agent_u64(q + 64), uc = ld_agent_u64(q + 128);
-        __builtin_amdgcn_s_sleep(6);
-        for (unsigned it = 0; it < 16 * kGsSpinLimit; ++it) {
-            const unsigned long long va = ld_agent_u64(q), vb = ld_agent_u64(q + 64), vc = ld_agent_u64(q + 128);
-            if (ua != kGsSentinel && ub != kGsSentinel && uc != kGsSentinel) {
-                a = __longlong_as_double((long long)ua);
-                b = __longlong_as_double((long long)ub);
-                c = __longlong_as_double((long long)uc);
-                return true;
-            }
-            ua = va;
-            ub = vb;
-            uc = vc;
-            if ((it & 1023u) == 1023u && __hip_atomic_load(flags + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-        }
-    }
-#endif
     for (unsigned it = 0; it < 16 * kGsSpinLimit; ++it) {
         const unsigned long long ua = ld_agent_u64(q), ub = ld_agent_u64(q + 64), uc = ld_agent_u64(q + 128);
         if (ua != kGsSentinel && ub != kGsSentinel && uc != kGsSentinel) {
