@@ -143,6 +143,13 @@ void mpmc_hip_destroy(mpmc_hip_ctx *ctx);
  *                          0 = the host sorts the ranking metric in every call;
  *   "fuse_tensor"         accepted and ignored (round 2's A/B switch for the expanded sub-diagonal tiles, which the chain
  *                          kernel no longer uses: it holds P_t = M_t D T(t,t-1), built in the block-inverse launch);
+ *   "gs_lags"             (default 3; 2 .. 4): how many of a block's most recent sources the chain kernel takes from cached
+ *                          matrices L(k)_t = M_t D T(t,t-k) (k = 1: main workgroup's registers, k >= 2: one auxiliary workgroup
+ *                          each) instead of from the pair coefficients; rounding of the sweep differs at 1e-13 between values; a
+ *                          view that is rebuilt as a whole in consecutive calls (grand-canonical chains) uses 2;
+ *   "gs_build_fork"       (default 1): the chain-data rebuild of the main stream's view runs on a stream of its own beside the
+ *                          step's next launches (views of 24+ blocks; 2 = always, 0 = in the main stream; bit-neutral);
+ *   "gs_side_waves"       (default 16; 8): workgroup size of the OTHER view's incremental rebuild in the side stream (bit-neutral);
  *   "rank_view_side"      (default 1): polar_gs_ranked calls in which the host sorts the metric (after a grand-canonical
  *                          edit, or when the speculated walk was wrong): the ranked view is (re)built on the side
  *                          stream beside the first sweep instead of on the main stream behind it (0 = main; A/B);
