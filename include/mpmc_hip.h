@@ -149,7 +149,8 @@ void mpmc_hip_destroy(mpmc_hip_ctx *ctx);
  *                          view that is rebuilt as a whole in consecutive calls (grand-canonical chains) uses 2;
  *   "gs_build_fork"       (default 1): the chain-data rebuild of the main stream's view runs on a stream of its own beside the
  *                          step's next launches (views of 24+ blocks; 2 = always, 0 = in the main stream; bit-neutral);
- *   "gs_side_waves"       (default 16; 8): workgroup size of the OTHER view's incremental rebuild in the side stream (bit-neutral);
+ *   "gs_side_waves"       (default 0): the OTHER view's incremental rebuild in the side stream takes the fastest workgroup geometry
+ *                          that leaves the concurrently running chain kernel its compute units; 16 = always 16-wave workgroups (bit-neutral);
  *   "rank_view_side"      (default 1): polar_gs_ranked calls in which the host sorts the metric (after a grand-canonical
  *                          edit, or when the speculated walk was wrong): the ranked view is (re)built on the side
  *                          stream beside the first sweep instead of on the main stream behind it (0 = main; A/B);

@@ -345,7 +345,8 @@ struct mpmc_hip_ctx {
     hipEvent_t ev_bfork = nullptr, ev_bjoin = nullptr;
     bool build_join_pending = false;       // the main stream has not yet waited for the builder launch of this call
     int opt_gs_build_fork = 1;             // "gs_build_fork": 0 = the builder in the main stream (A/B)
-    int opt_gs_side_waves = 16;            // "gs_side_waves": waves per workgroup of the OTHER view's rebuild in the side stream (8 or 16)
+    int opt_gs_side_waves = 0;             // "gs_side_waves": 16 = the OTHER view's rebuild in the side stream always with 16-wave workgroups;
+                                           // 0 = the fastest geometry that leaves the chain kernel its CUs
     int *h_order = nullptr;               // pinned staging of set_sweep_order (2 x max_npad ints)
     hipEvent_t ev_order = nullptr;
     double *h_rank = nullptr;             // pinned, max_npad
@@ -562,7 +563,7 @@ extern "C" int mpmc_hip_set_option(mpmc_hip_ctx *c, const char *name, int value)
     else if (!strcmp(name, "gs_build_fork"))
         c->opt_gs_build_fork = value;
     else if (!strcmp(name, "gs_side_waves"))
-        c->opt_gs_side_waves = (value == 8) ? 8 : 16;
+        c->opt_gs_side_waves = (value == 16) ? 16 : 0;
     else if (!strcmp(name, "gs_lags")) {
         if (value < 2 || value > kGsMaxLag) return fail("mpmc_hip_set_option: gs_lags must be 2 .. %d", kGsMaxLag);
         if (value != c->opt_gs_lags) c->view[0].M_epoch = c->view[1].M_epoch = 0;  // (the matrices of the new lags are not there)
