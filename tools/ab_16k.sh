@@ -1,4 +1,5 @@
 #!/bin/bash
+# Production flags at 16 384 atoms on one box: this tree with 3 / 2 / 4 lags and round 2's chain kernel (tools/ab/libmpmc_hip_tnb.so)
 lib=mpmc_amd/csrc/libmpmc_hip.so
 cp $lib /tmp/ab_tree.so
 run() { env $2 python bench.py --workload spolprod_16384 --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null | python -c "
