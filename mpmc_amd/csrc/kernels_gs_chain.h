@@ -733,20 +733,17 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
         // complete in order: a poll issued behind 64 KB of tile loads waits for all of them -- measured, that made a tile
         // cost 2.7 us instead of 1.5) and looked at after the current tile's arithmetic; a workgroup that runs behind the
         // front finds them valid and never waits.
-        // A workgroup that keeps pace with the front asks too early (mu_{s+1} is published one block-time after mu_s): the
-        // request is repeated half-way through the tile's arithmetic (spec2), which saves the ~0.5 us of a dependent load
-        // per source whenever the value has arrived in between.
-        unsigned long long spec = kGsSentinel, spec2 = kGsSentinel;
+        // (A second look half-way through the tile's arithmetic -- for the workgroup that keeps pace with the front and asks too
+        //  early -- paid while w_t hung on the last far source by one block-time; with three lags that stage has slack, and every
+        //  extra reader of a freshly published block lengthens its hand-off to everybody else: without it the sweep is 1 us
+        //  shorter at 39 blocks and 3 % at 154, profiles/r03_gs/ab_logs/no_second_look.txt.)
+        unsigned long long spec = kGsSentinel;
         double spec_pos = 0.0;
         auto spec_issue = [&](int s) {
             if (tid < 192) {
                 if (!(p.ablate & 4)) spec = ld_agent_u64(reinterpret_cast<const unsigned long long *>(mu_of(s)) + 192 * (size_t)s + tid);
                 spec_pos = ((tid < 64) ? p.px : (tid < 128 ? p.py : p.pz))[64 * s + lane];
             }
-            spec2 = kGsSentinel;
-        };
-        auto spec_again = [&](int s) {
-            if (tid < 192 && !(p.ablate & 4)) spec2 = ld_agent_u64(reinterpret_cast<const unsigned long long *>(mu_of(s)) + 192 * (size_t)s + tid);
         };
         // (LDS-only barriers: __syncthreads() would also wait for every global load of the wave -- the quarters of the next
         //  tile requested a moment ago -- i.e. put a memory round trip, ~0.45 us by the stamps, between two tiles)
@@ -754,13 +751,20 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
             lds_barrier();            // the previous tile's readers are done with smu / sps
             if (tid < 192) {
                 bool ok = true;
-                if (spec == kGsSentinel) spec = spec2;
                 double v = __longlong_as_double((long long)spec);
                 if (p.ablate & 4)
                     v = 1e-3;
-                else if (spec == kGsSentinel)  // not there yet: poll, one load at a time (the tail has block-times of slack;
-                                               // urgent polls are kept for the critical section, see the rationing note)
-                    v = poll_value<false>(mu_of(s) + 192 * (size_t)s + tid, p.flags, ok);
+                else {
+                    // Not there yet (this workgroup keeps pace with the front): ONE lane per wave waits for the block, the
+                    // others look again only when it has seen it -- ~35 workgroups wait for the same block at any time, and 192
+                    // lanes each polling their own word were ~1 400 requests per microsecond on the 24 lines the critical
+                    // consumer is waiting for too.
+                    const bool need = spec == kGsSentinel;
+                    if (__builtin_amdgcn_ballot_w64(need) != 0ull) {
+                        if (lane == 0) (void)poll_value<false>(mu_of(s) + 192 * (size_t)s + 64 * w, p.flags, ok);
+                        if (need) v = poll_value<false>(mu_of(s) + 192 * (size_t)s + tid, p.flags, ok);
+                    }
+                }
                 smu[tid] = v;
                 sps[tid] = spec_pos;
                 if (!ok) s_ok = 0;
@@ -799,7 +803,6 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(GsChain p) {
                 }
                 // this quarter's registers take the next tile's quarter at once: between 3/4 and 4/4 of a tile in flight
                 if (n + 1 < ns) load_quarter(n + 1, part);
-                if (part == 2 && n + 1 < ns) spec_again(n + 1);
             }
             if (n >= ns - 2) GS_STAMP(n == ns - 1 ? 5 : 3);
         }
